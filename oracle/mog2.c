@@ -1,0 +1,318 @@
+/*
+ * mog2.c -- ORACLE (test infrastructure): Zivkovic Gaussian-mixture background
+ * subtraction exactly as cv::BackgroundSubtractorMOG2 (OpenCV 3.1.0,
+ * modules/video/src/bgfg_gaussmix2.cpp: BackgroundSubtractorMOG2Impl::apply,
+ * MOG2Invoker::operator(), detectShadowGMM) computes it on the CPU.
+ *
+ * Stands in for:  BackgroundSubtractorMOG.cpp:82-83 (creation, all defaults)
+ *                 BackgroundSubtractorMOG.cpp:124   (apply)
+ *                 BackgroundSubtractorMOG.cpp:125   (frame.setTo(0, mask == 0))
+ *
+ * OpenCV is not in /root/reference; the algorithm is restated from the
+ * published source.  PARITY UNPINNED by the reference.
+ *
+ * Build with -ffp-contract=off: the x86-64 baseline OpenCV build has no FMA,
+ * so every multiply and add below rounds separately, in this order.
+ */
+#include "oat_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float weight; float variance; } gmm_t;   /* OpenCV's struct GMM */
+
+struct oat_mog2 {
+    int rows, cols, ch;
+    oat_mog2_params p;
+    int nframes;
+    gmm_t *gmm;          /* rows*cols*nmixtures, AoS like OpenCV's bgmodel      */
+    float *mean;         /* rows*cols*nmixtures*ch                              */
+    uint8_t *modes_used; /* rows*cols                                           */
+};
+
+void oat_mog2_default_params(oat_mog2_params *p)
+{
+    /* bgfg_gaussmix2.cpp defaults: defaultHistory2=500, defaultVarThreshold2=16,
+     * defaultNMixtures2=5, defaultBackgroundRatio2=0.9, defaultVarThresholdGen2=9,
+     * defaultVarInit2=15, defaultVarMax2=5*15, defaultVarMin2=4, defaultfCT2=0.05,
+     * defaultnShadowDetection2=127, defaultfTau=0.5; createBackgroundSubtractorMOG2
+     * default detectShadows=true. */
+    p->history = 500;
+    p->nmixtures = 5;
+    p->var_threshold = 16.0f;
+    p->background_ratio = 0.9f;
+    p->var_threshold_gen = 3.0f * 3.0f;
+    p->var_init = 15.0f;
+    p->var_min = 4.0f;
+    p->var_max = 5.0f * 15.0f;
+    p->ct = 0.05f;
+    p->detect_shadows = 1;
+    p->shadow_value = 127;
+    p->tau = 0.5f;
+}
+
+oat_mog2 *oat_mog2_create(int rows, int cols, int channels, const oat_mog2_params *p)
+{
+    oat_mog2 *m = (oat_mog2 *)calloc(1, sizeof(*m));
+    if (!m) return NULL;
+    m->rows = rows; m->cols = cols; m->ch = channels;
+    if (p) m->p = *p; else oat_mog2_default_params(&m->p);
+    size_t n = (size_t)rows * cols;
+    m->gmm = (gmm_t *)calloc(n * m->p.nmixtures, sizeof(gmm_t));
+    m->mean = (float *)calloc(n * m->p.nmixtures * channels, sizeof(float));
+    m->modes_used = (uint8_t *)calloc(n, 1);
+    m->nframes = 0;
+    return m;
+}
+
+void oat_mog2_destroy(oat_mog2 *m)
+{
+    if (!m) return;
+    free(m->gmm); free(m->mean); free(m->modes_used); free(m);
+}
+
+int oat_mog2_nframes(const oat_mog2 *m) { return m->nframes; }
+const uint8_t *oat_mog2_modes_used(const oat_mog2 *m) { return m->modes_used; }
+
+void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float *mean)
+{
+    size_t n = (size_t)m->rows * m->cols * m->p.nmixtures;
+    for (size_t i = 0; i < n; i++) {
+        if (weight) weight[i] = m->gmm[i].weight;
+        if (variance) variance[i] = m->gmm[i].variance;
+    }
+    if (mean) memcpy(mean, m->mean, n * m->ch * sizeof(float));
+}
+
+/* detectShadowGMM (bgfg_gaussmix2.cpp) */
+static int detect_shadow_gmm(const float *data, int nchannels, int nmodes,
+                             const gmm_t *gmm, const float *mean,
+                             float Tb, float TB, float tau)
+{
+    float tWeight = 0;
+    for (int mode = 0; mode < nmodes; mode++, mean += nchannels) {
+        gmm_t g = gmm[mode];
+        float numerator = 0.0f;
+        float denominator = 0.0f;
+        for (int c = 0; c < nchannels; c++) {
+            numerator += data[c] * mean[c];
+            denominator += mean[c] * mean[c];
+        }
+        /* no division by zero allowed */
+        if (denominator == 0)
+            return 0;
+        /* if tau < a < 1 then also check the colour distortion */
+        if (numerator <= denominator && numerator >= tau * denominator) {
+            float a = numerator / denominator;
+            float dist2a = 0.0f;
+            for (int c = 0; c < nchannels; c++) {
+                float dD = a * mean[c] - data[c];
+                dist2a += dD * dD;
+            }
+            if (dist2a < Tb * g.variance * a * a)
+                return 1;
+        }
+        tWeight += g.weight;
+        if (tWeight > TB)
+            return 0;
+    }
+    return 0;
+}
+
+/* MOG2Invoker::operator()(Range) for rows [y0,y1) */
+static void mog2_rows(oat_mog2 *m, const uint8_t *image, uint8_t *maskimg,
+                      float alphaT, float prune, int y0, int y1)
+{
+    const int ncols = m->cols, nchannels = m->ch, nmixtures = m->p.nmixtures;
+    const float Tb = m->p.var_threshold, TB = m->p.background_ratio, Tg = m->p.var_threshold_gen;
+    const float varInit = m->p.var_init, varMin = m->p.var_min, varMax = m->p.var_max;
+    const float tau = m->p.tau;
+    const int detectShadows = m->p.detect_shadows;
+    const uint8_t shadowVal = m->p.shadow_value;
+    const float alpha1 = 1.f - alphaT;
+    float dData[4];
+    float px[4];
+
+    for (int y = y0; y < y1; y++) {
+        const uint8_t *src = image + (size_t)y * ncols * nchannels;
+        float *mean = m->mean + (size_t)ncols * nmixtures * nchannels * y;
+        gmm_t *gmm = m->gmm + (size_t)ncols * nmixtures * y;
+        uint8_t *modesUsed = m->modes_used + (size_t)ncols * y;
+        uint8_t *mask = maskimg + (size_t)ncols * y;
+
+        for (int x = 0; x < ncols; x++, src += nchannels, gmm += nmixtures, mean += nmixtures * nchannels) {
+            /* src->row(y).convertTo(CV_32F) */
+            for (int c = 0; c < nchannels; c++) px[c] = (float)src[c];
+            const float *data = px;
+
+            int background = 0;
+            int fitsPDF = 0;
+            int nmodes = modesUsed[x];
+            float totalWeight = 0.f;
+            float *mean_m = mean;
+
+            for (int mode = 0; mode < nmodes; mode++, mean_m += nchannels) {
+                float weight = alpha1 * gmm[mode].weight + prune;
+                int swap_count = 0;
+                if (!fitsPDF) {
+                    float var = gmm[mode].variance;
+                    float dist2;
+                    if (nchannels == 3) {
+                        dData[0] = mean_m[0] - data[0];
+                        dData[1] = mean_m[1] - data[1];
+                        dData[2] = mean_m[2] - data[2];
+                        dist2 = dData[0] * dData[0] + dData[1] * dData[1] + dData[2] * dData[2];
+                    } else {
+                        dist2 = 0.f;
+                        for (int c = 0; c < nchannels; c++) {
+                            dData[c] = mean_m[c] - data[c];
+                            dist2 += dData[c] * dData[c];
+                        }
+                    }
+                    /* background? - Tb - usually larger than Tg */
+                    if (totalWeight < TB && dist2 < Tb * var)
+                        background = 1;
+                    /* check fit */
+                    if (dist2 < Tg * var) {
+                        fitsPDF = 1;
+                        weight += alphaT;
+                        float k = alphaT / weight;
+                        for (int c = 0; c < nchannels; c++)
+                            mean_m[c] -= k * dData[c];
+                        float varnew = var + k * (dist2 - var);
+                        varnew = varnew > varMin ? varnew : varMin;   /* MAX(varnew,varMin) */
+                        varnew = varnew < varMax ? varnew : varMax;   /* MIN(varnew,varMax) */
+                        gmm[mode].variance = varnew;
+                        /* sort: only the matched mode may have to move up */
+                        for (int i = mode; i > 0; i--) {
+                            if (weight < gmm[i - 1].weight)
+                                break;
+                            swap_count++;
+                            gmm_t tg = gmm[i]; gmm[i] = gmm[i - 1]; gmm[i - 1] = tg;
+                            for (int c = 0; c < nchannels; c++) {
+                                float t = mean[i * nchannels + c];
+                                mean[i * nchannels + c] = mean[(i - 1) * nchannels + c];
+                                mean[(i - 1) * nchannels + c] = t;
+                            }
+                        }
+                    }
+                }
+                /* check prune */
+                if (weight < -prune) {
+                    weight = 0.0f;
+                    nmodes--;
+                }
+                gmm[mode - swap_count].weight = weight;
+                totalWeight += weight;
+            }
+
+            /* renormalise weights */
+            totalWeight = 1.f / totalWeight;
+            for (int mode = 0; mode < nmodes; mode++)
+                gmm[mode].weight *= totalWeight;
+
+            /* make a new mode if needed */
+            if (!fitsPDF && alphaT > 0.f) {
+                int mode = nmodes == nmixtures ? nmixtures - 1 : nmodes++;
+                if (nmodes == 1)
+                    gmm[mode].weight = 1.f;
+                else {
+                    gmm[mode].weight = alphaT;
+                    for (int i = 0; i < nmodes - 1; i++)
+                        gmm[i].weight *= alpha1;
+                }
+                for (int c = 0; c < nchannels; c++)
+                    mean[mode * nchannels + c] = data[c];
+                gmm[mode].variance = varInit;
+                for (int i = nmodes - 1; i > 0; i--) {
+                    if (alphaT < gmm[i - 1].weight)
+                        break;
+                    gmm_t tg = gmm[i]; gmm[i] = gmm[i - 1]; gmm[i - 1] = tg;
+                    for (int c = 0; c < nchannels; c++) {
+                        float t = mean[i * nchannels + c];
+                        mean[i * nchannels + c] = mean[(i - 1) * nchannels + c];
+                        mean[(i - 1) * nchannels + c] = t;
+                    }
+                }
+            }
+
+            modesUsed[x] = (uint8_t)nmodes;
+            mask[x] = background ? 0 :
+                (detectShadows && detect_shadow_gmm(data, nchannels, nmodes, gmm, mean, Tb, TB, tau)) ?
+                shadowVal : 255;
+        }
+    }
+}
+
+/* BackgroundSubtractorMOG2Impl::apply prologue: (re)initialise, ++nframes,
+ * effective learning rate; returns alphaT / prune. */
+static void mog2_begin(oat_mog2 *m, double learningRate, float *alphaT, float *prune)
+{
+    int needToInitialize = m->nframes == 0 || learningRate >= 1;
+    if (needToInitialize) {
+        size_t n = (size_t)m->rows * m->cols;
+        memset(m->gmm, 0, n * m->p.nmixtures * sizeof(gmm_t));
+        memset(m->mean, 0, n * m->p.nmixtures * m->ch * sizeof(float));
+        memset(m->modes_used, 0, n);
+        m->nframes = 0;
+    }
+    ++m->nframes;
+    int lim = 2 * m->nframes < m->p.history ? 2 * m->nframes : m->p.history;
+    learningRate = (learningRate >= 0 && m->nframes > 1) ? learningRate : 1. / lim;
+    *alphaT = (float)learningRate;
+    *prune = (float)(-learningRate * m->p.ct);   /* product formed in double */
+}
+
+void oat_mog2_apply(oat_mog2 *m, const uint8_t *image, uint8_t *mask, double learningRate)
+{
+    float alphaT, prune;
+    mog2_begin(m, learningRate, &alphaT, &prune);
+    mog2_rows(m, image, mask, alphaT, prune, 0, m->rows);
+}
+
+static void set_to_zero_where_mask0(uint8_t *frame, const uint8_t *mask, size_t n, int ch)
+{
+    for (size_t i = 0; i < n; i++)
+        if (mask[i] == 0)
+            for (int c = 0; c < ch; c++) frame[i * ch + c] = 0;
+}
+
+void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learningRate)
+{
+    oat_mog2_apply(m, frame, mask, learningRate);
+    set_to_zero_where_mask0(frame, mask, (size_t)m->rows * m->cols, m->ch);
+}
+
+typedef struct {
+    oat_mog2 *m; uint8_t *frame; uint8_t *mask; float alphaT, prune; int y0, y1;
+} mog2_job;
+
+static void *mog2_worker(void *arg)
+{
+    mog2_job *j = (mog2_job *)arg;
+    mog2_rows(j->m, j->frame, j->mask, j->alphaT, j->prune, j->y0, j->y1);
+    size_t off = (size_t)j->y0 * j->m->cols;
+    set_to_zero_where_mask0(j->frame + off * j->m->ch, j->mask + off,
+                            (size_t)(j->y1 - j->y0) * j->m->cols, j->m->ch);
+    return NULL;
+}
+
+void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learningRate, int nthreads)
+{
+    if (nthreads <= 1) { oat_mog2_filter(m, frame, mask, learningRate); return; }
+    if (nthreads > 256) nthreads = 256;
+    float alphaT, prune;
+    mog2_begin(m, learningRate, &alphaT, &prune);
+    pthread_t th[256];
+    mog2_job jobs[256];
+    int rows = m->rows;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].m = m; jobs[t].frame = frame; jobs[t].mask = mask;
+        jobs[t].alphaT = alphaT; jobs[t].prune = prune;
+        jobs[t].y0 = (int)((long)rows * t / nthreads);
+        jobs[t].y1 = (int)((long)rows * (t + 1) / nthreads);
+        pthread_create(&th[t], NULL, mog2_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}

@@ -1,0 +1,177 @@
+/*
+ * oat_oracle.h -- CPU ORACLE for the Oat hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is a plain-C restatement of the arithmetic that jonnew/Oat's
+ *   framefilt mog  ->  framefilt col (BGR2HSV)  ->  posidet hsv|thresh
+ * chain performs on the CPU.  Oat itself is 3-15 lines of glue per stage; the
+ * arithmetic lives in OpenCV 3.x (pinned by the reference's README.md:1613 to
+ * 3.1.0), which is NOT vendored under /root/reference and is not installed in
+ * this image.  Every function below therefore cites (a) the reference call
+ * site it stands in for and (b) the OpenCV 3.1.0 routine whose published
+ * algorithm it restates.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors / known-answer tests
+ * for this path (its tests cover lib/shmemdf only) and
+ * neither the reference nor OpenCV can be built here.  The oracle is pinned
+ * only by hand-derived known answers (tests/golden/) and by cross-checking
+ * two independent formulations of the contour stage.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.  The product path (oat_amd/) never does.
+ */
+#ifndef OAT_ORACLE_H
+#define OAT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ MOG2 -- */
+
+/* cv::createBackgroundSubtractorMOG2() defaults, as used (all defaults) by
+ * BackgroundSubtractorMOG.cpp:82-83. */
+typedef struct {
+    int history;          /* 500  */
+    int nmixtures;        /* 5    */
+    float var_threshold;  /* Tb = 16   */
+    float background_ratio; /* TB = 0.9 */
+    float var_threshold_gen; /* Tg = 9 */
+    float var_init;       /* 15 */
+    float var_min;        /* 4  */
+    float var_max;        /* 75 = 5*var_init */
+    float ct;             /* 0.05 complexity reduction */
+    int detect_shadows;   /* 1 */
+    uint8_t shadow_value; /* 127 */
+    float tau;            /* 0.5 */
+} oat_mog2_params;
+
+void oat_mog2_default_params(oat_mog2_params *p);
+
+typedef struct oat_mog2 oat_mog2;
+
+/* channels: 3 (BGR) or 1 (GREY) */
+oat_mog2 *oat_mog2_create(int rows, int cols, int channels, const oat_mog2_params *p);
+void oat_mog2_destroy(oat_mog2 *m);
+
+/* cv::BackgroundSubtractorMOG2::apply(image, fgmask, learningRate)
+ * (BackgroundSubtractorMOG.cpp:124).  mask in {0,127,255}. */
+void oat_mog2_apply(oat_mog2 *m, const uint8_t *image, uint8_t *mask, double learning_rate);
+
+/* BackgroundSubtractorMOG::filter CPU branch, BackgroundSubtractorMOG.cpp:124-125:
+ * apply() then frame.setTo(0, mask == 0).  frame is modified in place; mask is
+ * an rows*cols scratch/out buffer. */
+void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning_rate);
+
+/* row-parallel variant of oat_mog2_filter (what OpenCV's parallel_for_ does);
+ * results identical, rows are independent. */
+void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
+
+/* State inspection (tests / parity): per pixel, `nmixtures` entries. */
+int oat_mog2_nframes(const oat_mog2 *m);
+const uint8_t *oat_mog2_modes_used(const oat_mog2 *m);         /* rows*cols */
+/* weight[p*nmix+k], variance[p*nmix+k], mean[(p*nmix+k)*ch+c] */
+void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float *mean);
+
+/* ------------------------------------------------------------- colour ----- */
+
+/* cv::cvtColor(frame, out, COLOR_BGR2HSV) for CV_8UC3 (ColorConvert.cpp:104;
+ * OpenCV RGB2HSV_b, hrange 180, hsv_shift 12). */
+void oat_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npixels);
+
+/* cv::inRange on 3-channel / 1-channel 8U data with integer scalar bounds
+ * (HSVDetector.cpp:146-149, SimpleThreshold.cpp:171-174).  Bounds inclusive;
+ * lo > hi or lo > 255 -> empty; hi saturates to 255. */
+void oat_inrange3(const uint8_t *src, size_t npixels, const int lo[3], const int hi[3], uint8_t *dst);
+void oat_inrange1(const uint8_t *src, size_t npixels, int lo, int hi, uint8_t *dst);
+
+/* ---------------------------------------------------------- morphology ---- */
+
+/* cv::erode / cv::dilate with getStructuringElement(MORPH_RECT, Size(k,k)),
+ * default anchor (k/2,k/2), 1 iteration, BORDER_CONSTANT with
+ * morphologyDefaultBorderValue (HSVDetector.cpp:152-156, :253-273).
+ * k <= 0 is not a legal call (Oat switches the stage off instead); k == 1 copies.
+ * src and dst may alias. */
+void oat_erode_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k);
+void oat_dilate_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k);
+
+/* ------------------------------------------------------------ contours ---- */
+
+typedef struct {
+    int start_x, start_y;   /* pixel where the raster scan met the border    */
+    int npoints;            /* CHAIN_APPROX_SIMPLE vertex count              */
+    int first_point;        /* offset into oat_contours.points (x,y pairs)   */
+    double a00, a10, a01;   /* raw Green sums of cv::moments(contourMoments) */
+    double m00, m10, m01;   /* spatial moments as cv::moments returns them   */
+} oat_contour;
+
+typedef struct {
+    int count;
+    oat_contour *c;         /* in LIST order = reverse discovery order       */
+    int *points;            /* x0,y0,x1,y1,...                               */
+    int npoints_total;
+} oat_contours;
+
+/* cv::findContours(img, contours, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) of
+ * OpenCV 3.1.0 (DetectorFunc.cpp:41-43) followed by cv::moments on each
+ * contour (DetectorFunc.cpp:50).  img (rows*cols u8, nonzero = foreground)
+ * is destroyed exactly as the reference warns (DetectorFunc.cpp:40). */
+oat_contours *oat_find_contours_external(uint8_t *img, int rows, int cols);
+void oat_contours_free(oat_contours *cs);
+
+typedef struct {
+    int valid;          /* Position2D::position_valid                        */
+    double x, y;        /* Position2D::position                              */
+    double area;        /* object_area_ out-parameter of siftContours        */
+    /* diagnostics (not part of the reference's output) */
+    int64_t a00, a10, a01;
+    int32_t first_pixel;    /* raster index of the winning component's first pixel, -1 if none */
+} oat_detection;
+
+/* oat::siftContours, DetectorFunc.cpp:31-66 (destroys thr). */
+void oat_sift_contours(uint8_t *thr, int rows, int cols, double min_area, double max_area,
+                       oat_detection *out);
+
+/* Order-free restatement of the same thing: 8-connected
+ * foreground labels, 4-connected "outside" background, directed crack edges,
+ * exact int64 Green sums.  This is the formulation the HIP kernels implement;
+ * tests prove it equal to oat_sift_contours.  Does not modify thr. */
+void oat_sift_cracks(const uint8_t *thr, int rows, int cols, double min_area, double max_area,
+                     oat_detection *out);
+
+/* ----------------------------------------------------- detector chains ---- */
+
+typedef struct {
+    int h_lo, h_hi, s_lo, s_hi, v_lo, v_hi;   /* HSVDetector.h:86-88 defaults 0..256 */
+    int erode;      /* 0 = off (HSVDetector.cpp:42)   */
+    int dilate;     /* 10 default on (HSVDetector.cpp:43) */
+    double min_area, max_area;                /* HSVDetector.h:93-94 */
+} oat_hsv_params;
+
+void oat_hsv_default_params(oat_hsv_params *p);
+
+/* HSVDetector::detectPosition, HSVDetector.cpp:142-173 (tuning GUI excluded).
+ * hsv: rows*cols*3.  thr_out (rows*cols) receives the post-morphology
+ * threshold image BEFORE findContours destroys it (may be NULL). */
+void oat_detect_hsv(const uint8_t *hsv, int rows, int cols, const oat_hsv_params *p,
+                    uint8_t *thr_out, oat_detection *out);
+
+/* SimpleThreshold::detectPosition, SimpleThreshold.cpp:114-134,169-182.
+ * grey: rows*cols.  Uses h_lo/h_hi of p as t_min/t_max. */
+void oat_detect_thresh(const uint8_t *grey, int rows, int cols, const oat_hsv_params *p,
+                       uint8_t *thr_out, oat_detection *out);
+
+/* Whole chain for one BGR frame: mog filter -> BGR2HSV -> detect_hsv.
+ * (frameserve -> framefilt mog -> framefilt col -C HSV -> posidet hsv.)
+ * frame is consumed (modified).  scratch must hold rows*cols*5 bytes.
+ * nthreads > 1 row-parallelises the per-pixel stages. */
+void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double learning_rate,
+                    const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
+                    oat_detection *out, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,160 @@
+/*
+ * pixels.c -- ORACLE (test infrastructure): the element-wise and stencil
+ * stages between background subtraction and contour analysis.
+ *
+ *   oat_bgr2hsv     ColorConvert.cpp:101-107  cv::cvtColor(.., COLOR_BGR2HSV)
+ *                   = OpenCV 3.1.0 imgproc/color.cpp RGB2HSV_b (hrange 180)
+ *   oat_inrange3/1  HSVDetector.cpp:146-149 / SimpleThreshold.cpp:171-174
+ *                   = core/arithm.cpp cv::inRange with scalar bounds on 8U
+ *   oat_erode_rect  HSVDetector.cpp:152-153 (+ :253-262 structuring element)
+ *   oat_dilate_rect HSVDetector.cpp:155-156 (+ :264-273)
+ *                   = imgproc/morph.cpp, MORPH_RECT k x k, anchor (k/2,k/2),
+ *                     BORDER_CONSTANT, morphologyDefaultBorderValue()
+ *
+ * PARITY UNPINNED by the reference (no tests for this path); pinned by the
+ * hand-derived known answers in tests/golden/.
+ */
+#include "oat_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------- BGR2HSV ---- */
+
+static int sdiv_table[256];
+static int hdiv_table180[256];
+static int hsv_tables_ready = 0;
+
+static void hsv_tables_init(void)
+{
+    const int hsv_shift = 12;
+    sdiv_table[0] = hdiv_table180[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        /* saturate_cast<int>(double) == cvRound == round-half-to-even */
+        sdiv_table[i] = (int)lrint((255 << hsv_shift) / (1. * i));
+        hdiv_table180[i] = (int)lrint((180 << hsv_shift) / (6. * i));
+    }
+    hsv_tables_ready = 1;
+}
+
+void oat_bgr2hsv(const uint8_t *src, uint8_t *dst, size_t n)
+{
+    const int hsv_shift = 12;
+    const int hr = 180;
+    if (!hsv_tables_ready) hsv_tables_init();
+    for (size_t i = 0; i < n; i++, src += 3, dst += 3) {
+        int b = src[0], g = src[1], r = src[2];
+        int h, s, v = b;
+        int vmin = b, diff;
+        int vr, vg;
+
+        if (g > v) v = g;
+        if (r > v) v = r;
+        if (g < vmin) vmin = g;
+        if (r < vmin) vmin = r;
+
+        diff = v - vmin;
+        vr = v == r ? -1 : 0;
+        vg = v == g ? -1 : 0;
+
+        s = (diff * sdiv_table[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        h = (vr & (g - b)) +
+            (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+        h = (h * hdiv_table180[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        h += h < 0 ? hr : 0;
+
+        dst[0] = (uint8_t)(h < 0 ? 0 : h > 255 ? 255 : h);   /* saturate_cast<uchar> */
+        dst[1] = (uint8_t)s;
+        dst[2] = (uint8_t)v;
+    }
+}
+
+/* ------------------------------------------------------------- inRange ---- */
+
+/* cv::inRange, scalar bounds, 8U source: the bounds are converted to int; a
+ * channel with lo > hi, lo > 255 or hi < 0 can never match; otherwise bounds
+ * saturate to [0,255] and both ends are inclusive. */
+static void inrange_bounds(int lo, int hi, int *l, int *h)
+{
+    if (lo > hi || lo > 255 || hi < 0) { *l = 1; *h = 0; return; }
+    *l = lo < 0 ? 0 : lo;
+    *h = hi > 255 ? 255 : hi;
+}
+
+void oat_inrange3(const uint8_t *src, size_t n, const int lo[3], const int hi[3], uint8_t *dst)
+{
+    int l[3], h[3];
+    for (int c = 0; c < 3; c++) inrange_bounds(lo[c], hi[c], &l[c], &h[c]);
+    for (size_t i = 0; i < n; i++, src += 3) {
+        int ok = src[0] >= l[0] && src[0] <= h[0] &&
+                 src[1] >= l[1] && src[1] <= h[1] &&
+                 src[2] >= l[2] && src[2] <= h[2];
+        dst[i] = ok ? 255 : 0;
+    }
+}
+
+void oat_inrange1(const uint8_t *src, size_t n, int lo, int hi, uint8_t *dst)
+{
+    int l, h;
+    inrange_bounds(lo, hi, &l, &h);
+    for (size_t i = 0; i < n; i++)
+        dst[i] = (src[i] >= l && src[i] <= h) ? 255 : 0;
+}
+
+/* ---------------------------------------------------------- morphology ---- */
+
+/* One k x k rectangular min (erode) or max (dilate).  Window of output (x,y)
+ * is x' in [x-a, x-a+k-1], y' likewise, a = k/2 (integer division): OpenCV
+ * does not reflect the element for dilation.  Samples outside the image take
+ * the constant border: 255 for erode, 0 for dilate. */
+static void morph_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k, int is_erode)
+{
+    size_t n = (size_t)rows * cols;
+    if (k <= 1) { if (dst != src) memmove(dst, src, n); return; }
+    const int a = k / 2;
+    const uint8_t border = is_erode ? 255 : 0;
+    uint8_t *tmp = (uint8_t *)malloc(n);
+    /* row pass */
+    for (int y = 0; y < rows; y++) {
+        const uint8_t *s = src + (size_t)y * cols;
+        uint8_t *t = tmp + (size_t)y * cols;
+        for (int x = 0; x < cols; x++) {
+            uint8_t acc = border;
+            int first = 1;
+            for (int j = 0; j < k; j++) {
+                int xx = x - a + j;
+                uint8_t v = (xx < 0 || xx >= cols) ? border : s[xx];
+                if (first) { acc = v; first = 0; }
+                else if (is_erode ? (v < acc) : (v > acc)) acc = v;
+            }
+            t[x] = acc;
+        }
+    }
+    /* column pass */
+    for (int y = 0; y < rows; y++) {
+        uint8_t *d = dst + (size_t)y * cols;
+        for (int x = 0; x < cols; x++) {
+            uint8_t acc = border;
+            int first = 1;
+            for (int j = 0; j < k; j++) {
+                int yy = y - a + j;
+                uint8_t v = (yy < 0 || yy >= rows) ? border : tmp[(size_t)yy * cols + x];
+                if (first) { acc = v; first = 0; }
+                else if (is_erode ? (v < acc) : (v > acc)) acc = v;
+            }
+            d[x] = acc;
+        }
+    }
+    free(tmp);
+}
+
+void oat_erode_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k)
+{
+    morph_rect(src, dst, rows, cols, k, 1);
+}
+
+void oat_dilate_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k)
+{
+    morph_rect(src, dst, rows, cols, k, 0);
+}
