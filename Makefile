@@ -1,0 +1,32 @@
+# Builds the product library (HIP, gfx950 only) and the test oracle (plain C).
+#   make            -> oat_amd/lib/liboatgpu.so + oracle/liboat_oracle.so
+#   make host       -> C++ drop-in binaries under build/bin
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off is a PARITY requirement (the reference's CPU build rounds every
+# mul/add of the MOG2 update separately), not a tuning choice.
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result -Wno-unused-value
+CSRC     = oat_amd/csrc
+LIB      = oat_amd/lib/liboatgpu.so
+OBJS     = $(CSRC)/kernels_mog.o $(CSRC)/kernels_blob.o $(CSRC)/oatgpu_api.o
+
+all: $(LIB) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/oatgpu_internal.h include/oatgpu.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p oat_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+host: $(LIB)
+	$(MAKE) -C oat_amd/host
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle host clean

@@ -1,0 +1,198 @@
+/*
+ * oatgpu.h -- C ABI of liboatgpu.so: the MI355X (gfx950) implementation of Oat's
+ * per-frame image hot path
+ *
+ *      framefilt mog  ->  framefilt col (BGR2HSV)  ->  posidet hsv | thresh
+ *
+ * Plain pointers and sizes only; no C++ or torch types, no exceptions.  Every
+ * entry point names the reference interface it replaces (paths relative to
+ * jonnew/Oat).  INTEGRATION.md shows the binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - return 0 on success, a negative OATGPU_E_* code on failure;
+ *     oatgpu_last_error() gives the text.
+ *   - the caller owns every host buffer; the context owns all device state
+ *     (MOG2 model planes, bit masks, label tables, result ring).
+ *   - one context per host thread (not re-entrant); work is issued on one HIP
+ *     stream per context (oatgpu_set_stream adopts an external one).
+ *   - pixel buffers are packed, rows*cols*channels bytes, no row padding
+ *     (lib/datatypes/Frame.h:92-103, lib/shmemdf/Sink.h:289-290).
+ *   - "stream" below = one camera stream (an independent Oat pipeline), not a
+ *     HIP stream, unless it says HIP.
+ */
+#ifndef OATGPU_H
+#define OATGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OATGPU_ABI_VERSION 1
+
+enum {
+    OATGPU_OK = 0,
+    OATGPU_E_INVALID = -1,    /* bad argument / configuration               */
+    OATGPU_E_HIP = -2,        /* HIP runtime error (text in last_error)     */
+    OATGPU_E_NOMEM = -3,
+    OATGPU_E_RING_FULL = -4,  /* track_enqueue without a free result slot   */
+    OATGPU_E_RING_EMPTY = -5, /* track_collect with nothing outstanding     */
+    OATGPU_E_NODEVICE = -6    /* no usable HIP device                       */
+};
+
+/* Context configuration.  Fill with oatgpu_default_config() first; it sets the
+ * reference's defaults:
+ *   MOG2   cv::createBackgroundSubtractorMOG2() with all defaults
+ *          (src/framefilter/BackgroundSubtractorMOG.cpp:82-83)
+ *   hsv    HSVDetector.h:77-94 / HSVDetector.cpp:34-47 (all-pass thresholds,
+ *          erode off, dilate 10, area [0, DBL_MAX))
+ */
+typedef struct oatgpu_config {
+    int32_t device;            /* HIP device ordinal                          */
+    int32_t n_streams;         /* camera streams batched in this context      */
+    int32_t rows, cols;        /* frame geometry, identical for all streams   */
+    int32_t ring_depth;        /* outstanding track_enqueue results (>=1)     */
+
+    /* --- MOG2 (BackgroundSubtractorMOG.cpp:82-83) --- */
+    int32_t history;           /* 500 */
+    int32_t nmixtures;         /* 5 (1..5 supported)                          */
+    float var_threshold;       /* Tb 16   */
+    float background_ratio;    /* TB 0.9  */
+    float var_threshold_gen;   /* Tg 9    */
+    float var_init;            /* 15      */
+    float var_min;             /* 4       */
+    float var_max;             /* 75      */
+    float ct;                  /* 0.05    */
+    float tau;                 /* 0.5     */
+    int32_t detect_shadows;    /* 1       */
+    int32_t shadow_value;      /* 127     */
+
+    /* --- detector (HSVDetector.cpp:77-140, SimpleThreshold.cpp:71-112) --- */
+    int32_t h_lo, h_hi;        /* -H [min,max] in [0,256]; also -T for thresh */
+    int32_t s_lo, s_hi;        /* -S */
+    int32_t v_lo, v_hi;        /* -V */
+    int32_t erode;             /* -e, 0 = off                                 */
+    int32_t dilate;            /* -d, 0 = off                                 */
+    double min_area, max_area; /* -a [min,max)                                */
+} oatgpu_config;
+
+/* What posidet writes into oat::Position2D (src/positiondetector/DetectorFunc.cpp:46,58-60)
+ * plus the raw integer Green sums the centroid is derived from. */
+typedef struct oatgpu_position {
+    int32_t valid;             /* Position2D::position_valid                  */
+    int32_t first_pixel;       /* raster index of the blob's first pixel, -1  */
+    double x, y;               /* Position2D::position (pixels)               */
+    double area;               /* siftContours' area out-parameter            */
+    int64_t a00, a10, a01;     /* exact contour sums (cv::moments internals)  */
+} oatgpu_position;
+
+/* Per-stage device time accumulated while profiling is enabled (HIP events on
+ * the context's HIP stream). */
+typedef struct oatgpu_profile {
+    int64_t steps;             /* track steps measured                        */
+    double mog_ms;             /* fused MOG2+mask+HSV+inRange kernel          */
+    double morph_ms;           /* erode + dilate                              */
+    double blob_ms;            /* labelling + contour sums + selection        */
+    double total_ms;           /* first event to last event of each step      */
+} oatgpu_profile;
+
+typedef struct oatgpu_ctx oatgpu_ctx;
+
+int oatgpu_abi_version(void);
+int oatgpu_default_config(oatgpu_config *cfg);
+
+/* Object lifetime == the reference component's (MOG model and scratch are
+ * members: BackgroundSubtractorMOG.h:72-73, HSVDetector.h:83). */
+oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg);   /* NULL on failure; oatgpu_last_error(NULL) */
+void oatgpu_destroy(oatgpu_ctx *ctx);
+const char *oatgpu_last_error(const oatgpu_ctx *ctx);
+
+/* HIP stream plumbing (hipStream_t passed as void*). */
+int oatgpu_set_stream(oatgpu_ctx *ctx, void *hip_stream);
+void *oatgpu_get_stream(oatgpu_ctx *ctx);
+int oatgpu_synchronize(oatgpu_ctx *ctx);
+
+/* Re-configure the detector between frames (what the reference's tuning GUI
+ * mutates: HSVDetector.cpp:175-251). */
+int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
+                        int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
+                        double min_area, double max_area);
+
+/* ---- stage-by-stage operators (host buffers), one call == one reference call ---- */
+
+/* cv::BackgroundSubtractorMOG2::apply(frame, mask, learning_rate)
+ * (BackgroundSubtractorMOG.cpp:124).  fgmask_out: rows*cols, values {0,127,255}. */
+int oatgpu_mog_apply(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *bgr_in,
+                     uint8_t *fgmask_out, double learning_rate);
+
+/* BackgroundSubtractorMOG::filter(cv::Mat&) CPU-branch semantics
+ * (BackgroundSubtractorMOG.cpp:114-127): apply + frame.setTo(0, mask == 0).
+ * bgr_out may equal bgr_in. */
+int oatgpu_mog_filter(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *bgr_in,
+                      uint8_t *bgr_out, double learning_rate);
+
+/* ColorConvert::filter with COLOR_BGR2HSV (ColorConvert.cpp:101-107). */
+int oatgpu_bgr2hsv(oatgpu_ctx *ctx, const uint8_t *bgr_in, uint8_t *hsv_out);
+
+/* HSVDetector::detectPosition (HSVDetector.cpp:142-173): hsv_in rows*cols*3. */
+int oatgpu_detect_hsv(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *hsv_in,
+                      oatgpu_position *out);
+
+/* SimpleThreshold::detectPosition (SimpleThreshold.cpp:114-134): grey_in rows*cols;
+ * uses h_lo/h_hi as -T [min,max]. */
+int oatgpu_detect_thresh(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *grey_in,
+                         oatgpu_position *out);
+
+/* ---- fused hot path: mog + setTo + BGR2HSV + inRange + erode + dilate + blob ---- */
+
+/* One frame for EVERY stream of the context (the whole chain
+ * FrameFilter::process -> ColorConvert -> PositionDetector::process,
+ * FrameFilter.cpp:59-98, PositionDetector.cpp:58-99, minus the shm hand-offs).
+ * frames_host[i] -> rows*cols*3 BGR bytes of stream i.  out[n_streams]. */
+int oatgpu_track_batch(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n,
+                       double learning_rate, oatgpu_position *out);
+
+/* Same with the frames already resident in device memory:
+ * frames_dev = n_streams*rows*cols*3 bytes, stream-major. */
+int oatgpu_track_batch_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate,
+                           oatgpu_position *out);
+
+/* Pipelined form: enqueue returns at once; collect returns results in enqueue
+ * order (exactly one result set per enqueued frame set, SURVEY.md 8b token
+ * discipline).  Up to ring_depth enqueues may be outstanding. */
+int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate);
+int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
+int oatgpu_track_outstanding(const oatgpu_ctx *ctx);
+
+/* ---- parity taps / model checkpoint (not in the reference; for tests and resume) ---- */
+
+enum {
+    OATGPU_TAP_THRESHOLD = 0,  /* inRange output (after the fused kernel)        */
+    OATGPU_TAP_MORPH = 1,      /* after erode/dilate == reference threshold_frame_ */
+    OATGPU_TAP_FINAL = 2       /* after the 1-px frame zeroing findContours does */
+};
+/* Unpacks the device bit mask of the last processed frame of a stream to
+ * rows*cols bytes {0,255}. */
+int oatgpu_read_mask(oatgpu_ctx *ctx, int32_t stream_ix, int32_t which, uint8_t *out);
+
+/* MOG2 model of one stream in the oracle's (OpenCV's) logical layout:
+ * modes_used[rows*cols], weight/variance[rows*cols*nmix], mean[rows*cols*nmix*3].
+ * Entries of unused modes (>= modes_used) are unspecified on get. */
+int oatgpu_mog_get_state(oatgpu_ctx *ctx, int32_t stream_ix, uint8_t *modes_used, float *weight,
+                         float *variance, float *mean, int32_t *nframes);
+int oatgpu_mog_set_state(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *modes_used,
+                         const float *weight, const float *variance, const float *mean,
+                         int32_t nframes);
+
+/* ---- measurement ---- */
+int oatgpu_profile_enable(oatgpu_ctx *ctx, int32_t on);
+int oatgpu_profile_read(oatgpu_ctx *ctx, oatgpu_profile *out);   /* synchronises */
+int oatgpu_profile_reset(oatgpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OATGPU_H */

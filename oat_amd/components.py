@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Class and method names follow jonnew/Oat so that the parity tests read like the
+reference's call sites:
+
+    BackgroundSubtractorMOG.filter(frame)      src/framefilter/BackgroundSubtractorMOG.cpp:114-127
+    ColorConvert.filter(frame)                 src/framefilter/ColorConvert.cpp:101-107
+    HSVDetector.detectPosition(frame, pos)     src/positiondetector/HSVDetector.cpp:142-173
+    SimpleThreshold.detectPosition(frame, pos) src/positiondetector/SimpleThreshold.cpp:114-134
+
+``HotPath`` is the fused, batched form (N camera streams, one launch per stage).
+All pixel work happens in liboatgpu.so on the GPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import ffi
+
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+@dataclass
+class Position2D:
+    """The fields posidet writes into oat::Position2D (lib/datatypes/Position2D.h:112-127)."""
+    position_valid: bool = False
+    x: float = 0.0
+    y: float = 0.0
+    area: float = 0.0          # siftContours' object_area out-parameter
+    a00: int = 0
+    a10: int = 0
+    a01: int = 0
+    first_pixel: int = -1
+
+    @staticmethod
+    def from_c(p):
+        return Position2D(bool(p.valid), p.x, p.y, p.area, p.a00, p.a10, p.a01, p.first_pixel)
+
+
+def _frame(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.shape != shape:
+        raise ValueError(f"expected frame of shape {shape}, got {a.shape}")
+    return a
+
+
+class _Context:
+    """Owns one oatgpu_ctx."""
+
+    def __init__(self, rows, cols, n_streams=1, device=0, ring_depth=4, **overrides):
+        self.lib = ffi.load()
+        cfg = ffi.Config()
+        self.lib.oatgpu_default_config(C.byref(cfg))
+        cfg.rows, cfg.cols, cfg.n_streams, cfg.device, cfg.ring_depth = rows, cols, n_streams, device, ring_depth
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.rows, self.cols, self.n_streams = rows, cols, n_streams
+        self.ctx = self.lib.oatgpu_create(C.byref(cfg))
+        if not self.ctx:
+            raise ffi.OatGpuError(-1, (self.lib.oatgpu_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.oatgpu_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        ffi.check(self.lib, self.ctx, rc)
+
+    # -- taps ------------------------------------------------------------
+    def read_mask(self, which=ffi.TAP_MORPH, stream=0):
+        out = np.empty((self.rows, self.cols), np.uint8)
+        self._chk(self.lib.oatgpu_read_mask(self.ctx, stream, which, ffi.u8(out)))
+        return out
+
+    def mog_state(self, stream=0):
+        n, k = self.rows * self.cols, self.cfg.nmixtures
+        nm = np.empty(n, np.uint8)
+        w = np.empty((n, k), np.float32)
+        v = np.empty((n, k), np.float32)
+        m = np.empty((n, k, 3), np.float32)
+        nf = C.c_int32(0)
+        self._chk(self.lib.oatgpu_mog_get_state(self.ctx, stream, ffi.u8(nm), ffi.f32(w), ffi.f32(v), ffi.f32(m),
+                                                C.byref(nf)))
+        return nm, w, v, m, nf.value
+
+    def set_mog_state(self, nm, w, v, m, nframes, stream=0):
+        nm = np.ascontiguousarray(nm, np.uint8)
+        w, v, m = (np.ascontiguousarray(a, np.float32) for a in (w, v, m))
+        self._chk(self.lib.oatgpu_mog_set_state(self.ctx, stream, ffi.u8(nm), ffi.f32(w), ffi.f32(v), ffi.f32(m),
+                                                int(nframes)))
+
+
+class BackgroundSubtractorMOG(_Context):
+    """framefilt mog.  ``adaptation_coeff`` is the reference's -a option (default 0)."""
+
+    def __init__(self, rows, cols, adaptation_coeff=0.0, **kw):
+        if not 0.0 <= adaptation_coeff <= 1.0:
+            raise ValueError("adaptation-coeff must be in [0, 1]")   # BackgroundSubtractorMOG.cpp:86-88
+        super().__init__(rows, cols, **kw)
+        self.learning_coeff_ = float(adaptation_coeff)
+
+    def filter(self, frame, stream=0):
+        """In place, like FrameFilter::filter(cv::Mat&); also returns the frame."""
+        f = _frame(frame, (self.rows, self.cols, 3))
+        out = frame if (isinstance(frame, np.ndarray) and frame.flags.c_contiguous and frame.dtype == np.uint8) else f
+        self._chk(self.lib.oatgpu_mog_filter(self.ctx, stream, ffi.u8(f), ffi.u8(out), self.learning_coeff_))
+        return out
+
+    def apply(self, frame, learning_rate=None, stream=0):
+        """cv::BackgroundSubtractorMOG2::apply: returns the {0,127,255} mask."""
+        f = _frame(frame, (self.rows, self.cols, 3))
+        mask = np.empty((self.rows, self.cols), np.uint8)
+        lr = self.learning_coeff_ if learning_rate is None else float(learning_rate)
+        self._chk(self.lib.oatgpu_mog_apply(self.ctx, stream, ffi.u8(f), ffi.u8(mask), lr))
+        return mask
+
+
+class ColorConvert(_Context):
+    """framefilt col -C HSV."""
+
+    def filter(self, frame):
+        f = _frame(frame, (self.rows, self.cols, 3))
+        out = np.empty_like(f)
+        self._chk(self.lib.oatgpu_bgr2hsv(self.ctx, ffi.u8(f), ffi.u8(out)))
+        return out
+
+
+class _Detector(_Context):
+    def _set(self, **kw):
+        c = self.cfg
+        for k, v in kw.items():
+            setattr(c, k, v)
+        self._chk(self.lib.oatgpu_set_detector(self.ctx, c.h_lo, c.h_hi, c.s_lo, c.s_hi, c.v_lo, c.v_hi,
+                                               c.erode, c.dilate, c.min_area, c.max_area))
+
+
+class HSVDetector(_Detector):
+    """posidet hsv.  Options follow HSVDetector.cpp:49-75 (-H -S -V -e -d -a)."""
+
+    def __init__(self, rows, cols, h_thresh=(0, 256), s_thresh=(0, 256), v_thresh=(0, 256),
+                 erode=0, dilate=10, area=(0.0, DBL_MAX), **kw):
+        super().__init__(rows, cols, h_lo=h_thresh[0], h_hi=h_thresh[1], s_lo=s_thresh[0], s_hi=s_thresh[1],
+                         v_lo=v_thresh[0], v_hi=v_thresh[1], erode=erode, dilate=dilate,
+                         min_area=area[0], max_area=area[1], **kw)
+
+    def detectPosition(self, frame, position=None, stream=0):
+        f = _frame(frame, (self.rows, self.cols, 3))
+        p = ffi.Position()
+        self._chk(self.lib.oatgpu_detect_hsv(self.ctx, stream, ffi.u8(f), C.byref(p)))
+        return _merge(position, p)
+
+
+class SimpleThreshold(_Detector):
+    """posidet thresh.  Options follow SimpleThreshold.cpp:49-69 (-T -e -d -a); erode/dilate default off."""
+
+    def __init__(self, rows, cols, thresh=(0, 256), erode=0, dilate=0, area=(0.0, DBL_MAX), **kw):
+        super().__init__(rows, cols, h_lo=thresh[0], h_hi=thresh[1], erode=erode, dilate=dilate,
+                         min_area=area[0], max_area=area[1], **kw)
+
+    def detectPosition(self, frame, position=None, stream=0):
+        f = _frame(frame, (self.rows, self.cols))
+        p = ffi.Position()
+        self._chk(self.lib.oatgpu_detect_thresh(self.ctx, stream, ffi.u8(f), C.byref(p)))
+        return _merge(position, p)
+
+
+def _merge(position, p):
+    """siftContours only writes x/y when a blob is found (DetectorFunc.cpp:46,58-60)."""
+    new = Position2D.from_c(p)
+    if position is None:
+        return new
+    position.position_valid = new.position_valid
+    position.area = new.area
+    if new.position_valid:
+        position.x, position.y = new.x, new.y
+    position.a00, position.a10, position.a01, position.first_pixel = new.a00, new.a10, new.a01, new.first_pixel
+    return position
+
+
+class HotPath(_Context):
+    """The fused chain for N camera streams: mog + setTo + BGR2HSV + inRange + erode + dilate + blob."""
+
+    def __init__(self, rows, cols, n_streams=1, adaptation_coeff=0.0, h_thresh=(0, 256), s_thresh=(0, 256),
+                 v_thresh=(0, 256), erode=0, dilate=10, area=(0.0, DBL_MAX), **kw):
+        super().__init__(rows, cols, n_streams=n_streams, h_lo=h_thresh[0], h_hi=h_thresh[1], s_lo=s_thresh[0],
+                         s_hi=s_thresh[1], v_lo=v_thresh[0], v_hi=v_thresh[1], erode=erode, dilate=dilate,
+                         min_area=area[0], max_area=area[1], **kw)
+        self.learning_coeff_ = float(adaptation_coeff)
+        self._pos = (ffi.Position * n_streams)()
+
+    def _out(self):
+        return [Position2D.from_c(p) for p in self._pos]
+
+    def track(self, frames):
+        """frames: sequence of n_streams host arrays (rows, cols, 3)."""
+        fs = [_frame(f, (self.rows, self.cols, 3)) for f in frames]
+        ptrs = (ffi._u8p * len(fs))(*[ffi.u8(f) for f in fs])
+        self._chk(self.lib.oatgpu_track_batch(self.ctx, ptrs, len(fs), self.learning_coeff_, self._pos))
+        return self._out()
+
+    def track_dev(self, dev_ptr):
+        """dev_ptr: device address of n_streams*rows*cols*3 bytes (e.g. torch tensor .data_ptr())."""
+        self._chk(self.lib.oatgpu_track_batch_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_, self._pos))
+        return self._out()
+
+    def enqueue_dev(self, dev_ptr):
+        self._chk(self.lib.oatgpu_track_enqueue_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_))
+
+    def collect(self):
+        self._chk(self.lib.oatgpu_track_collect(self.ctx, self._pos))
+        return self._out()
+
+    def outstanding(self):
+        return self.lib.oatgpu_track_outstanding(self.ctx)
+
+    def set_stream(self, hip_stream):
+        self._chk(self.lib.oatgpu_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._chk(self.lib.oatgpu_synchronize(self.ctx))
+
+    def profile(self, on=True):
+        self._chk(self.lib.oatgpu_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.oatgpu_profile_reset(self.ctx))
+
+    def profile_read(self):
+        p = ffi.Profile()
+        self._chk(self.lib.oatgpu_profile_read(self.ctx, C.byref(p)))
+        return dict(steps=p.steps, mog_ms=p.mog_ms, morph_ms=p.morph_ms, blob_ms=p.blob_ms, total_ms=p.total_ms)

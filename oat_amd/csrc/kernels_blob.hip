@@ -1,0 +1,446 @@
+// kernels_blob.hip -- K2..K5: the back half of posidet on BIT-PACKED masks.
+//
+//   cv::erode / cv::dilate, MORPH_RECT k x k     (HSVDetector.cpp:152-156)
+//   cv::findContours(RETR_EXTERNAL, ...)          (DetectorFunc.cpp:41-43)
+//   cv::moments(contour)                          (DetectorFunc.cpp:50)
+//   the largest-area-in-window selection          (DetectorFunc.cpp:45-65)
+//
+// The reference follows borders sequentially.  Here the same numbers come from
+// an order-free formulation (proved equal to the sequential one by the CPU
+// tests, tests/test_oracle_contours_crosscheck.py):
+//   * a mask row is a string of 64-bit words (1 bit/pixel, 1080p row = 30 words);
+//     morphology is shifts and AND/OR on words;
+//   * connected components are found over horizontal RUNS, not pixels: the
+//     union-find node of a run is the raster index of its first pixel, so the
+//     parent table is touched only at run heads.  Foreground runs merge
+//     8-connected, background runs 4-connected, in the same pass;
+//   * the root of every component is its smallest head = its first pixel in
+//     raster order, which is exactly the reference's tie-break key; the
+//     background component of pixel 0 (root 0) is "outside" (the image frame is
+//     zeroed first, as OpenCV 3.1 does), anything else is a hole;
+//   * each foreground pixel emits at most one directed polygon edge per side
+//     facing OUTSIDE background; exact int64 Green sums per root.
+#include "oatgpu_internal.h"
+
+namespace oatgpu {
+
+__device__ __forceinline__ int msb64(u64 v) { return 63 - __clzll((long long)v); }
+__device__ __forceinline__ int lsb64(u64 v) { return __ffsll((long long)v) - 1; }
+__device__ __forceinline__ u64 low_mask_incl(int i) { return (i >= 63) ? ~0ull : ((2ull << i) - 1ull); }
+
+// bits of word w that are real pixels (x < W)
+__device__ __forceinline__ u64 valid_bits(const Geom &g, int w)
+{
+    const int rem = g.W - w * 64;
+    return rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+}
+
+// ------------------------------------------------------------- morphology ----
+// One thread = one output word.  Window of output bit x is [x-a, x-a+k-1] in
+// both directions (a = k/2, not reflected); outside the image reads 1 for
+// erosion and 0 for dilation (morphologyDefaultBorderValue).  k <= 63.
+__global__ __launch_bounds__(256) void k_morph(Geom g, const u64 *src_all, u64 *dst_all, int k, int is_erode,
+                                               int first_stream)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.H * g.words) return;
+    const int s = first_stream + blockIdx.y;
+    const int y = t / g.words, w = t - y * g.words;
+    const u64 *src = src_all + (size_t)s * (g.Palloc >> 6);
+    u64 *dst = dst_all + (size_t)s * (g.Palloc >> 6);
+    const int a = k / 2;
+    const u64 ident = is_erode ? ~0ull : 0ull;
+    const u64 vlast = valid_bits(g, g.words - 1);
+
+    u64 ap = ident, ac = ident, an = ident;
+    for (int j = 0; j < k; ++j) {
+        const int yy = y - a + j;
+        if (yy < 0 || yy >= g.H) continue;          // border rows are the identity
+        const u64 *row = src + (size_t)yy * g.words;
+        u64 pw = w > 0 ? row[w - 1] : ident;
+        u64 cw = row[w];
+        u64 nw = (w + 1 < g.words) ? row[w + 1] : ident;
+        if (is_erode) {                              // padding bits beyond x = W-1 read as 1
+            if (w == g.words - 1) cw |= ~vlast;
+            if (w + 1 == g.words - 1) nw |= ~vlast;
+            ap &= pw; ac &= cw; an &= nw;
+        } else {
+            ap |= pw; ac |= cw; an |= nw;
+        }
+    }
+    u64 out = ident;
+    for (int j = 0; j < k; ++j) {
+        const int o = j - a;                         // out bit i takes in bit i+o
+        u64 v;
+        if (o == 0) v = ac;
+        else if (o > 0) v = (ac >> o) | (an << (64 - o));
+        else v = (ac << (-o)) | (ap >> (64 + o));
+        out = is_erode ? (out & v) : (out | v);
+    }
+    dst[(size_t)y * g.words + w] = out & valid_bits(g, w);
+}
+
+void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode, int first_stream,
+                  int n_streams, hipStream_t st)
+{
+    const int n = g.H * g.words;
+    hipLaunchKernelGGL(k_morph, dim3((n + 255) / 256, n_streams), dim3(256), 0, st, g, src, dst, k,
+                       is_erode ? 1 : 0, first_stream);
+}
+
+// ------------------------------------------------------------- row scan ------
+// One wavefront per image row, one lane per mask word (rows wider than 4096 px
+// loop in chunks of 64 words).  Writes the final mask (image frame zeroed, as
+// cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start x of
+// the run entering every word, and initialises the union-find at run heads.
+__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, BlobBuffers b, int first_stream)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= g.H) return;
+    const int s = first_stream + blockIdx.y;
+    const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
+    const u64 *src = src_all + woff;
+    u64 *fin = b.fin + woff;
+    u64 *trans = b.trans + woff;
+    int *carry = b.carry + (size_t)s * g.H * g.words + (size_t)y * g.words;
+    int *parent = b.parent + (size_t)s * g.Palloc;
+
+    if (y == 0 && lane == 0) b.best[s] = 0ull;
+
+    const bool frame_row = (y == 0) || (y == g.H - 1);
+    const int lastx = g.W - 1;
+    int chunk_carry = 0;        // start x of the last run seen so far
+    u64 chunk_prevbit = 0;      // pixel value just left of this chunk
+
+    for (int c0 = 0; c0 < g.words; c0 += 64) {
+        const int w = c0 + lane;
+        const bool active = w < g.words;
+        u64 F = 0;
+        if (active && !frame_row) {
+            F = src[w] & valid_bits(g, w);
+            if (w == 0) F &= ~1ull;
+            if (w == (lastx >> 6)) F &= ~(1ull << (lastx & 63));
+        }
+        // pixel left of bit 0: previous lane's bit 63
+        u64 up = __shfl_up(F, 1);
+        u64 prevbit = (lane == 0) ? chunk_prevbit : (up >> 63);
+        u64 T = F ^ ((F << 1) | prevbit);
+        if (w == 0) T |= 1ull;                       // a run starts at x = 0 by definition
+        T &= valid_bits(g, w);
+        if (!active) T = 0;
+
+        const u64 nz = __ballot(T != 0);
+        const u64 lower = nz & ((1ull << lane) - 1ull);
+        const int pl = lower ? msb64(lower) : 0;
+        const u64 Tp = __shfl(T, pl);
+        const int cin = lower ? ((c0 + pl) * 64 + msb64(Tp)) : chunk_carry;
+
+        if (active) {
+            fin[w] = F;
+            trans[w] = T;
+            carry[w] = cin;
+            u64 tt = T;
+            while (tt) {
+                const int i = lsb64(tt);
+                tt &= tt - 1;
+                const int head = y * g.Wp + w * 64 + i;
+                parent[head] = head;
+            }
+        }
+        // carry state into the next chunk (all lanes agree)
+        if (nz) {
+            const int hl = msb64(nz);
+            const u64 Th = __shfl(T, hl);
+            chunk_carry = (c0 + hl) * 64 + msb64(Th);
+        }
+        chunk_prevbit = __shfl(F, 63) >> 63;
+    }
+}
+
+// ------------------------------------------------------------ union-find -----
+// All accesses to parent[] inside the merge / flatten kernels are agent-scope
+// relaxed atomics: correct for any placement of workgroups on XCDs (per-XCD
+// L2s and per-CU L1s are not coherent for plain accesses).
+__device__ __forceinline__ int uf_ld(int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_min(int *p, int v)
+{
+    return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int uf_find(int *parent, int i)
+{
+    int cur = i;
+    int p = uf_ld(parent + cur);
+    while (p != cur) {
+        const int gp = uf_ld(parent + p);
+        if (gp != p) uf_min(parent + cur, gp);       // path halving (monotone, safe under races)
+        cur = p;
+        p = gp;
+    }
+    return cur;
+}
+
+__device__ __forceinline__ void uf_union(int *parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // a > b: hang a under b
+        const int old = uf_min(parent + a, b);
+        if (old == a) return;                           // a was still a root
+        a = old;                                        // lost a race: keep merging old with b
+    }
+}
+
+// head (first pixel, padded index) of the run that contains pixel (x, y)
+__device__ __forceinline__ int run_head(const Geom &g, const u64 *trans, const int *carry, int y, int x)
+{
+    const int w = x >> 6, i = x & 63;
+    const u64 t = trans[(size_t)y * g.words + w] & low_mask_incl(i);
+    const int sx = t ? (w * 64 + msb64(t)) : carry[(size_t)y * g.words + w];
+    return y * g.Wp + sx;
+}
+// same, with this word's T / carry already in registers
+__device__ __forceinline__ int run_head_w(const Geom &g, u64 Tw, int cw, int y, int w, int i)
+{
+    const u64 t = Tw & low_mask_incl(i);
+    const int sx = t ? (w * 64 + msb64(t)) : cw;
+    return y * g.Wp + sx;
+}
+
+// One thread = one word of row y (y >= 1): unite runs of row y with the runs
+// of row y-1 they touch.  Background: 4-connected.  Foreground: 8-connected.
+__global__ __launch_bounds__(256) void k_merge(Geom g, BlobBuffers b, int first_stream)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (g.H - 1) * g.words) return;
+    const int s = first_stream + blockIdx.y;
+    const int y = 1 + t / g.words, w = t % g.words;
+    const size_t soff = (size_t)s * (g.Palloc >> 6);
+    const u64 *fin = b.fin + soff;
+    const u64 *trans = b.trans + soff;
+    const int *carry = b.carry + (size_t)s * g.H * g.words;
+    int *parent = b.parent + (size_t)s * g.Palloc;
+
+    const size_t rc = (size_t)y * g.words, ru = (size_t)(y - 1) * g.words;
+    const u64 cur = fin[rc + w], up = fin[ru + w];
+    const u64 curP = w > 0 ? fin[rc + w - 1] : 0ull;
+    const u64 upP = w > 0 ? fin[ru + w - 1] : 0ull;
+    const u64 upN = (w + 1 < g.words) ? fin[ru + w + 1] : 0ull;
+    const u64 valid = valid_bits(g, w);
+    const u64 Tc = trans[rc + w], Tu = trans[ru + w];
+    const int cc = carry[rc + w], cu = carry[ru + w];
+
+    // --- background, vertical contacts; one union per contact run ---
+    u64 cb = ~cur & ~up & valid;
+    if (w > 0 && (cb & 1ull) && (((~curP & ~upP) >> 63) & 1ull))
+        cb &= cb + 1ull;                     // run continues from the previous word: its thread did it
+    while (cb) {
+        const int i = lsb64(cb);
+        uf_union(parent, run_head_w(g, Tc, cc, y, w, i), run_head_w(g, Tu, cu, y - 1, w, i));
+        cb &= cb + (cb & (~cb + 1ull));      // clear the lowest run of ones
+    }
+    if (cur == 0ull) return;
+
+    // --- foreground, vertical contacts ---
+    u64 cv = cur & up;
+    if (w > 0 && (cv & 1ull) && (((curP & upP) >> 63) & 1ull))
+        cv &= cv + 1ull;
+    while (cv) {
+        const int i = lsb64(cv);
+        uf_union(parent, run_head_w(g, Tc, cc, y, w, i), run_head_w(g, Tu, cu, y - 1, w, i));
+        cv &= cv + (cv & (~cv + 1ull));
+    }
+    // --- foreground, diagonal contacts not implied by a vertical one ---
+    u64 dl = cur & ((up << 1) | (upP >> 63)) & ~up;   // up pixel at x-1
+    while (dl) {
+        const int i = lsb64(dl);
+        dl &= dl - 1;
+        uf_union(parent, run_head_w(g, Tc, cc, y, w, i), run_head(g, trans, carry, y - 1, w * 64 + i - 1));
+    }
+    u64 dr = cur & ((up >> 1) | (upN << 63)) & ~up;   // up pixel at x+1
+    while (dr) {
+        const int i = lsb64(dr);
+        dr &= dr - 1;
+        uf_union(parent, run_head_w(g, Tc, cc, y, w, i), run_head(g, trans, carry, y - 1, w * 64 + i + 1));
+    }
+}
+
+// One thread = one word: every run head points straight at its root; roots of
+// foreground components get their accumulators cleared.
+__global__ __launch_bounds__(256) void k_flatten(Geom g, BlobBuffers b, int first_stream)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.H * g.words) return;
+    const int s = first_stream + blockIdx.y;
+    const int y = t / g.words, w = t - y * g.words;
+    const size_t soff = (size_t)s * (g.Palloc >> 6);
+    const u64 F = b.fin[soff + t];
+    u64 T = b.trans[soff + t];
+    int *parent = b.parent + (size_t)s * g.Palloc;
+    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+    while (T) {
+        const int i = lsb64(T);
+        T &= T - 1;
+        const int h = y * g.Wp + w * 64 + i;
+        const int r = uf_find(parent, h);
+        if (r != h) __hip_atomic_store(parent + h, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if ((F >> i) & 1ull) { acc[(size_t)h * 3] = 0; acc[(size_t)h * 3 + 1] = 0; acc[(size_t)h * 3 + 2] = 0; }
+    }
+}
+
+// One thread = one word of an interior row: Green sums over the directed edges
+// of foreground pixels that face OUTSIDE background (root 0).
+__global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_stream)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (g.H - 2) * g.words) return;
+    const int s = first_stream + blockIdx.y;
+    const int y = 1 + t / g.words, w = t % g.words;
+    const size_t soff = (size_t)s * (g.Palloc >> 6);
+    const u64 *fin = b.fin + soff;
+    const u64 *trans = b.trans + soff;
+    const int *carry = b.carry + (size_t)s * g.H * g.words;
+    const int *parent = b.parent + (size_t)s * g.Palloc;
+    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+
+    const size_t rc = (size_t)y * g.words, ru = rc - g.words, rd = rc + g.words;
+    const u64 cur = fin[rc + w];
+    if (cur == 0ull) return;
+    const bool hp = w > 0, hn = w + 1 < g.words;
+    const u64 U = fin[ru + w], D = fin[rd + w];
+    const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
+    const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
+    const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
+    const u64 L = (cur << 1) | (curP >> 63), R = (cur >> 1) | (curN << 63);
+    const u64 UL = (U << 1) | (upP >> 63), UR = (U >> 1) | (upN << 63);
+    const u64 DL = (D << 1) | (dnP >> 63), DR = (D >> 1) | (dnN << 63);
+
+    u64 cand = cur & ~(L & R & U & D);
+    const u64 Tc = trans[rc + w];
+    const int cc = carry[rc + w];
+
+    int label = -1;
+    long long s00 = 0, s10 = 0, s01 = 0;
+    while (cand) {
+        const int i = lsb64(cand);
+        cand &= cand - 1;
+        const int x = w * 64 + i;
+        const u64 bit = 1ull << i;
+        const int lab = parent[run_head_w(g, Tc, cc, y, w, i)];
+        if (lab != label) {
+            if (label >= 0 && (s00 | s10 | s01)) {
+                atomicAdd((unsigned long long *)&acc[(size_t)label * 3], (unsigned long long)s00);
+                atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 1], (unsigned long long)s10);
+                atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 2], (unsigned long long)s01);
+            }
+            label = lab; s00 = s10 = s01 = 0;
+        }
+        // side: neighbour bg pixel, then B (diagonal, first) and A (straight, second)
+        int qx, qy;
+        bool e;
+#define OAT_EDGE()                                                                    \
+        if (e) {                                                                      \
+            const int d = x * qy - qx * y;                                            \
+            s00 += d; s10 += (long long)d * (x + qx); s01 += (long long)d * (y + qy); \
+        }
+        if (!(L & bit) && parent[run_head(g, trans, carry, y, x - 1)] == 0) {        // left
+            e = true;
+            if (DL & bit) { qx = x - 1; qy = y + 1; } else if (D & bit) { qx = x; qy = y + 1; } else e = false;
+            OAT_EDGE()
+        }
+        if (!(D & bit) && parent[run_head(g, trans, carry, y + 1, x)] == 0) {        // bottom
+            e = true;
+            if (DR & bit) { qx = x + 1; qy = y + 1; } else if (R & bit) { qx = x + 1; qy = y; } else e = false;
+            OAT_EDGE()
+        }
+        if (!(R & bit) && parent[run_head(g, trans, carry, y, x + 1)] == 0) {        // right
+            e = true;
+            if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
+            OAT_EDGE()
+        }
+        if (!(U & bit) && parent[run_head(g, trans, carry, y - 1, x)] == 0) {        // top
+            e = true;
+            if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
+            OAT_EDGE()
+        }
+#undef OAT_EDGE
+    }
+    if (label >= 0 && (s00 | s10 | s01)) {
+        atomicAdd((unsigned long long *)&acc[(size_t)label * 3], (unsigned long long)s00);
+        atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 1], (unsigned long long)s10);
+        atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 2], (unsigned long long)s01);
+    }
+}
+
+// One thread = one word: every foreground root offers (|a00|, first pixel) as a
+// packed key; atomicMax keeps the largest area, ties -> the later first pixel
+// (the reference walks its reversed list with a strict '>').
+__global__ __launch_bounds__(256) void k_select(Geom g, BlobBuffers b, double min_area, double max_area,
+                                                int first_stream)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.H * g.words) return;
+    const int s = first_stream + blockIdx.y;
+    const int y = t / g.words, w = t - y * g.words;
+    const size_t soff = (size_t)s * (g.Palloc >> 6);
+    u64 heads = b.trans[soff + t] & b.fin[soff + t];
+    const int *parent = b.parent + (size_t)s * g.Palloc;
+    const long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+    while (heads) {
+        const int i = lsb64(heads);
+        heads &= heads - 1;
+        const int h = y * g.Wp + w * 64 + i;
+        if (parent[h] != h) continue;
+        const long long a00 = acc[(size_t)h * 3];
+        if (a00 == 0) continue;
+        const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
+        const double area = (double)mag * 0.5;        // m00 = a00 * (+-0.5), exact
+        if (area >= min_area && area < max_area)
+            atomicMax((unsigned long long *)&b.best[s], (mag << 32) | (u64)(unsigned)h);
+    }
+}
+
+__global__ void k_finish(Geom g, BlobBuffers b, ResultRec *results, int first_stream, int n_streams)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    const int s = first_stream + i;
+    const u64 key = b.best[s];
+    ResultRec r;
+    r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
+    if (key) {
+        const int h = (int)(key & 0xffffffffull);
+        const long long *acc = b.acc + ((size_t)s * g.Palloc + h) * 3;
+        r.a00 = acc[0]; r.a10 = acc[1]; r.a01 = acc[2];
+        const int y = h / g.Wp, x = h - y * g.Wp;
+        r.first_pixel = y * g.W + x;
+        r.valid = 1;
+    }
+    results[s] = r;
+}
+
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, double min_area, double max_area,
+                 ResultRec *results, int first_stream, int n_streams, hipStream_t st)
+{
+    const int nw = g.H * g.words;
+    hipLaunchKernelGGL(k_rowscan, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, b, first_stream);
+    if (g.H > 1)
+        hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
+                           first_stream);
+    hipLaunchKernelGGL(k_flatten, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, first_stream);
+    if (g.H > 2)
+        hipLaunchKernelGGL(k_green, dim3(((g.H - 2) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
+                           first_stream);
+    hipLaunchKernelGGL(k_select, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, min_area, max_area,
+                       first_stream);
+    hipLaunchKernelGGL(k_finish, dim3((n_streams + 63) / 64), dim3(64), 0, st, g, b, results, first_stream,
+                       n_streams);
+}
+
+}  // namespace oatgpu

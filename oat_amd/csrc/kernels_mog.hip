@@ -1,0 +1,410 @@
+// kernels_mog.hip -- K1: the fused per-pixel front half of the hot path for gfx950.
+//
+//   cv::BackgroundSubtractorMOG2::apply      (BackgroundSubtractorMOG.cpp:124)
+//   frame.setTo(0, mask == 0)                (BackgroundSubtractorMOG.cpp:125)
+//   cv::cvtColor(.., COLOR_BGR2HSV)          (ColorConvert.cpp:104)
+//   cv::inRange(hsv, lo, hi)                 (HSVDetector.cpp:146-149)
+//
+// in ONE pass over HBM: 3 B/px of BGR in, the 101 B/px Gaussian-mixture model
+// read and written in place, 1 bit/px of threshold mask out.  Bandwidth bound
+// (205 algorithmic B/px); no MFMA.  Design notes:
+//   * one lane owns four pixels 64 apart (see mog_slot in oatgpu_internal.h):
+//     every model plane is one 16-byte load and one 16-byte store per lane,
+//     and __ballot() over pixel j of the 64 lanes IS mask word j -- the
+//     threshold image never exists as bytes.
+//   * the per-pixel update keeps OpenCV's operation order exactly (compiled
+//     with -ffp-contract=off: every mul/add rounds on its own, like the
+//     reference's x86-64 build); the mixture lives in registers with fully
+//     unrolled, statically indexed mode loops (no scratch).
+//   * BGR->HSV uses the same integer tables as RGB2HSV_b, built once per block
+//     in LDS.
+#include "oatgpu_internal.h"
+
+namespace oatgpu {
+
+struct PxModel {
+    float w[kMaxMix];
+    float v[kMaxMix];
+    float m[kMaxMix][3];
+};
+
+__device__ __forceinline__ void swap_up(PxModel &s, int i)   // exchange modes i and i-1
+{
+    float t;
+    t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
+    t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
+}
+
+// MOG2Invoker's per-pixel body (OpenCV 3.1.0 bgfg_gaussmix2.cpp) on a register
+// resident mixture.  Returns the foreground-mask value {0, shadowVal, 255}.
+__device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, float x1, float x2,
+                                          const MogParams &P, float alphaT, float alpha1, float prune)
+{
+    bool background = false, fits = false;
+    int nmodes = nmodes_io;
+    float total = 0.f;
+
+#pragma unroll
+    for (int mode = 0; mode < kMaxMix; ++mode) {
+        if (mode < nmodes) {              // nmodes shrinks when a mode is pruned, as in the reference loop
+            float weight = alpha1 * s.w[mode] + prune;
+            bool fit_here = false;
+            if (!fits) {
+                const float var = s.v[mode];
+                const float d0 = s.m[mode][0] - x0;
+                const float d1 = s.m[mode][1] - x1;
+                const float d2 = s.m[mode][2] - x2;
+                const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+                if (total < P.TB && dist2 < P.Tb * var) background = true;
+                if (dist2 < P.Tg * var) {
+                    fits = true;
+                    fit_here = true;
+                    weight += alphaT;
+                    const float k = alphaT / weight;
+                    s.m[mode][0] -= k * d0;
+                    s.m[mode][1] -= k * d1;
+                    s.m[mode][2] -= k * d2;
+                    float varnew = var + k * (dist2 - var);
+                    varnew = varnew > P.varMin ? varnew : P.varMin;
+                    varnew = varnew < P.varMax ? varnew : P.varMax;
+                    s.v[mode] = varnew;
+                    // The reference bubbles the OLD weight up and then stores the new one
+                    // into the final slot; carrying the new weight along is the same state.
+                    s.w[mode] = weight;
+                    bool moving = true;
+#pragma unroll
+                    for (int i = mode; i > 0; --i) {
+                        if (moving) {
+                            if (weight < s.w[i - 1]) moving = false;
+                            else swap_up(s, i);
+                        }
+                    }
+                }
+            }
+            if (!fit_here) {
+                // (a matched mode has weight >= alpha*(1-CT) > -prune: never pruned)
+                if (weight < -prune) { weight = 0.f; nmodes--; }
+                s.w[mode] = weight;
+            }
+            total += weight;
+        }
+    }
+
+    // renormalise
+    const float inv = 1.f / total;
+#pragma unroll
+    for (int mode = 0; mode < kMaxMix; ++mode)
+        if (mode < nmodes) s.w[mode] *= inv;
+
+    // new mode
+    if (!fits && alphaT > 0.f) {
+        const int mode = (nmodes == P.nmix) ? P.nmix - 1 : nmodes++;
+        const bool first = (nmodes == 1);
+#pragma unroll
+        for (int i = 0; i < kMaxMix; ++i) {
+            if (!first && i < nmodes - 1) s.w[i] *= alpha1;
+            if (i == mode) {
+                s.w[i] = first ? 1.f : alphaT;
+                s.v[i] = P.varInit;
+                s.m[i][0] = x0; s.m[i][1] = x1; s.m[i][2] = x2;
+            }
+        }
+        bool moving = true;
+#pragma unroll
+        for (int i = kMaxMix - 1; i > 0; --i) {
+            if (moving && i <= nmodes - 1) {
+                if (alphaT < s.w[i - 1]) moving = false;
+                else swap_up(s, i);
+            }
+        }
+    }
+    nmodes_io = nmodes;
+
+    if (background) return 0;
+    int mask = 255;
+    if (P.detectShadows) {
+        // detectShadowGMM
+        float tW = 0.f;
+        bool done = false;
+#pragma unroll
+        for (int mode = 0; mode < kMaxMix; ++mode) {
+            if (!done && mode < nmodes) {
+                const float m0 = s.m[mode][0], m1 = s.m[mode][1], m2 = s.m[mode][2];
+                const float num = x0 * m0 + x1 * m1 + x2 * m2;
+                const float den = m0 * m0 + m1 * m1 + m2 * m2;
+                if (den == 0.f) {
+                    done = true;
+                } else {
+                    if (num <= den && num >= P.tau * den) {
+                        const float a = num / den;
+                        const float e0 = a * m0 - x0, e1 = a * m1 - x1, e2 = a * m2 - x2;
+                        const float dist2a = e0 * e0 + e1 * e1 + e2 * e2;
+                        if (dist2a < P.Tb * s.v[mode] * a * a) { mask = P.shadowVal; done = true; }
+                    }
+                    if (!done) {
+                        tW += s.w[mode];
+                        if (tW > P.TB) done = true;
+                    }
+                }
+            }
+        }
+    }
+    return mask;
+}
+
+// RGB2HSV_b tables: sdiv[i] = cvRound((255<<12)/i), hdiv[i] = cvRound((180<<12)/(6 i)).
+// Neither quotient ever lands on .5 (255<<12 = 2^12*255, 180<<12/6 = 2^13*15), so
+// round-half-even == floor(q + 1/2) == (2n + i) / (2i) in integers.
+__device__ __forceinline__ void hsv_tables_init(int *sdiv, int *hdiv)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        sdiv[i] = i ? (2 * (255 << 12) + i) / (2 * i) : 0;
+        hdiv[i] = i ? (2 * ((180 << 12) / 6) + i) / (2 * i) : 0;
+    }
+}
+
+__device__ __forceinline__ void bgr2hsv_px(int b, int g, int r, const int *sdiv, const int *hdiv,
+                                           int &h, int &s, int &v)
+{
+    v = max(b, max(g, r));
+    const int vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    s = (diff * sdiv[v] + (1 << 11)) >> 12;
+    int hh = (v == r) ? (g - b) : (v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff);
+    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;   // arithmetic shift, as the reference
+    hh += hh < 0 ? 180 : 0;
+    h = hh;
+}
+
+__device__ __forceinline__ bool in_range3(int a, int b, int c, const RangeParams &rp)
+{
+    return a >= rp.lo[0] && a <= rp.hi[0] && b >= rp.lo[1] && b <= rp.hi[1] &&
+           c >= rp.lo[2] && c <= rp.hi[2];
+}
+
+__global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+{
+    __shared__ int sdiv[256];
+    __shared__ int hdiv[256];
+    hsv_tables_init(sdiv, hdiv);
+    __syncthreads();
+
+    const int s = first_stream + blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int base = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256;
+    if (base >= g.P) return;                      // whole wave beyond the image (tail block)
+
+    const size_t npx = (size_t)g.H * g.W;
+    const uint8_t *frame = a.frames + (size_t)s * npx * 3;
+    float *st = a.state + (size_t)s * kMogPlanes * g.Palloc + base + 4 * lane;
+    uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + 4 * lane;
+
+    // ---- load the mixture of this lane's four pixels: 25 x 16 B ----
+    float W[kMaxMix][4], V[kMaxMix][4], M[kMaxMix][3][4];
+    int nmodes[4];
+    if (!a.fresh) {
+#pragma unroll
+        for (int k = 0; k < kMaxMix; ++k) {
+            *(float4 *)W[k] = *(const float4 *)(st + (size_t)k * g.Palloc);
+            *(float4 *)V[k] = *(const float4 *)(st + (size_t)(5 + k) * g.Palloc);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *(float4 *)M[k][c] = *(const float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc);
+        }
+        const uchar4 n4 = *(const uchar4 *)nm;
+        nmodes[0] = n4.x; nmodes[1] = n4.y; nmodes[2] = n4.z; nmodes[3] = n4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kMaxMix; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                W[k][j] = 0.f; V[k][j] = 0.f; M[k][0][j] = 0.f; M[k][1][j] = 0.f; M[k][2][j] = 0.f;
+            }
+        nmodes[0] = nmodes[1] = nmodes[2] = nmodes[3] = 0;
+    }
+
+    u64 words[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = base + 64 * j + lane;
+        const int y = p / g.Wp;
+        const int x = p - y * g.Wp;
+        const bool valid = (p < g.P) && (x < g.W);
+        const size_t fi = ((size_t)y * g.W + x) * 3;
+        int b = 0, gg = 0, r = 0;
+        if (valid) { b = frame[fi]; gg = frame[fi + 1]; r = frame[fi + 2]; }
+
+        PxModel pm;
+#pragma unroll
+        for (int k = 0; k < kMaxMix; ++k) {
+            pm.w[k] = W[k][j]; pm.v[k] = V[k][j];
+            pm.m[k][0] = M[k][0][j]; pm.m[k][1] = M[k][1][j]; pm.m[k][2] = M[k][2][j];
+        }
+        int n = nmodes[j];
+        int mask = 0;
+        if (valid)
+            mask = mog2_pixel(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune);
+        nmodes[j] = n;
+#pragma unroll
+        for (int k = 0; k < kMaxMix; ++k) {
+            W[k][j] = pm.w[k]; V[k][j] = pm.v[k];
+            M[k][0][j] = pm.m[k][0]; M[k][1][j] = pm.m[k][1]; M[k][2][j] = pm.m[k][2];
+        }
+
+        // frame.setTo(0, mask == 0): shadows (127) stay foreground
+        if (mask == 0) { b = 0; gg = 0; r = 0; }
+        if (valid && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
+        if (valid && a.out_bgr) {
+            uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * 3 + fi;
+            o[0] = (uint8_t)b; o[1] = (uint8_t)gg; o[2] = (uint8_t)r;
+        }
+        int hh, ss, vv;
+        bgr2hsv_px(b, gg, r, sdiv, hdiv, hh, ss, vv);
+        const bool thr = valid && in_range3(hh, ss, vv, a.rp);
+        words[j] = __ballot(thr);
+    }
+
+    // ---- store the mixture back ----
+#pragma unroll
+    for (int k = 0; k < kMaxMix; ++k) {
+        *(float4 *)(st + (size_t)k * g.Palloc) = *(const float4 *)W[k];
+        *(float4 *)(st + (size_t)(5 + k) * g.Palloc) = *(const float4 *)V[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *(float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc) = *(const float4 *)M[k][c];
+    }
+    *(uchar4 *)nm = make_uchar4((uint8_t)nmodes[0], (uint8_t)nmodes[1], (uint8_t)nmodes[2], (uint8_t)nmodes[3]);
+
+    if (a.thr_bits && lane < 4) {
+        const u64 wsel = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        a.thr_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6) + lane] = wsel;
+    }
+}
+
+void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
+{
+    dim3 grid(g.Palloc / 1024, n_streams);
+    hipLaunchKernelGGL(k_mog_fused, grid, dim3(256), 0, st, g, a, first_stream);
+}
+
+// ------------------------------------------------------------ small kernels --
+
+__global__ __launch_bounds__(256) void k_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx)
+{
+    __shared__ int sdiv[256];
+    __shared__ int hdiv[256];
+    hsv_tables_init(sdiv, hdiv);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        int h, s, v;
+        bgr2hsv_px(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2], sdiv, hdiv, h, s, v);
+        hsv[3 * i] = (uint8_t)h; hsv[3 * i + 1] = (uint8_t)s; hsv[3 * i + 2] = (uint8_t)v;
+    }
+}
+
+void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st)
+{
+    int blocks = (int)((npx + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_bgr2hsv, dim3(blocks), dim3(256), 0, st, bgr, hsv, npx);
+}
+
+// one wave = one mask word (64 pixels of one row)
+__global__ __launch_bounds__(256) void k_inrange_bits(Geom g, const uint8_t *frame, int channels,
+                                                      RangeParams rp, u64 *bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= (g.Palloc >> 6)) return;
+    const int p = word * 64 + lane;
+    const int y = p / g.Wp, x = p - y * g.Wp;
+    const bool valid = p < g.P && x < g.W;
+    bool thr = false;
+    if (valid) {
+        const size_t i = (size_t)y * g.W + x;
+        if (channels == 3) thr = in_range3(frame[3 * i], frame[3 * i + 1], frame[3 * i + 2], rp);
+        else { const int v = frame[i]; thr = v >= rp.lo[0] && v <= rp.hi[0]; }
+    }
+    const u64 w = __ballot(thr);
+    if (lane == 0) bits[word] = w;
+}
+
+void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
+                         u64 *bits, hipStream_t st)
+{
+    const int nwords = g.Palloc >> 6;
+    hipLaunchKernelGGL(k_inrange_bits, dim3((nwords + 3) / 4), dim3(256), 0, st, g, frame, channels, rp, bits);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_bits(Geom g, const u64 *bits, uint8_t *out)
+{
+    const size_t npx = (size_t)g.H * g.W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
+        const int p = y * g.Wp + x;
+        out[i] = ((bits[p >> 6] >> (p & 63)) & 1ull) ? 255 : 0;
+    }
+}
+
+void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st)
+{
+    size_t npx = (size_t)g.H * g.W;
+    int blocks = (int)((npx + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_unpack_bits, dim3(blocks), dim3(256), 0, st, g, bits, out);
+}
+
+// ---- model checkpoint: device planes <-> OpenCV's logical AoS order ----
+__global__ __launch_bounds__(256) void k_state_export(Geom g, const float *state, const uint8_t *nmodes, int nmix,
+                                                      uint8_t *modes_used, float *weight, float *variance,
+                                                      float *mean)
+{
+    const size_t npx = (size_t)g.H * g.W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
+        const int slot = mog_slot(y * g.Wp + x);
+        modes_used[i] = nmodes[slot];
+        for (int k = 0; k < nmix; ++k) {
+            weight[i * nmix + k] = state[(size_t)k * g.Palloc + slot];
+            variance[i * nmix + k] = state[(size_t)(5 + k) * g.Palloc + slot];
+            for (int c = 0; c < 3; ++c)
+                mean[(i * nmix + k) * 3 + c] = state[(size_t)(10 + 3 * k + c) * g.Palloc + slot];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint8_t *nmodes, int nmix,
+                                                      const uint8_t *modes_used, const float *weight,
+                                                      const float *variance, const float *mean)
+{
+    const size_t npx = (size_t)g.H * g.W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
+        const int slot = mog_slot(y * g.Wp + x);
+        nmodes[slot] = modes_used[i];
+        for (int k = 0; k < nmix; ++k) {
+            state[(size_t)k * g.Palloc + slot] = weight[i * nmix + k];
+            state[(size_t)(5 + k) * g.Palloc + slot] = variance[i * nmix + k];
+            for (int c = 0; c < 3; ++c)
+                state[(size_t)(10 + 3 * k + c) * g.Palloc + slot] = mean[(i * nmix + k) * 3 + c];
+        }
+    }
+}
+
+void launch_state_export(const Geom &g, const float *state, const uint8_t *nmodes, int nmix,
+                         uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_state_export, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, modes_used, weight,
+                       variance, mean);
+}
+
+void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix, const uint8_t *modes_used,
+                         const float *weight, const float *variance, const float *mean, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_state_import, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, modes_used, weight,
+                       variance, mean);
+}
+
+}  // namespace oatgpu

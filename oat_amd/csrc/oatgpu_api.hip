@@ -1,0 +1,620 @@
+// oatgpu_api.hip -- the C ABI of include/oatgpu.h over the gfx950 kernels.
+//
+// Host-side orchestration only: geometry, the MOG2 learning-rate schedule
+// (BackgroundSubtractorMOG2Impl::apply prologue), kernel sequencing on one HIP
+// stream, the pinned result ring, and contourMoments' double-precision
+// epilogue.  No CPU fallback for any pixel work: every entry point either runs
+// the HIP kernels or fails with an error code.
+#include "../../include/oatgpu.h"
+#include "oatgpu_internal.h"
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace oatgpu;
+
+static thread_local std::string g_last_error;
+
+struct ProfStep { hipEvent_t e[4]; };
+
+struct oatgpu_ctx {
+    oatgpu_config cfg;
+    Geom g;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // device memory
+    float *state = nullptr;
+    uint8_t *nmodes = nullptr;
+    uint8_t *frames = nullptr;     // staging [n][H*W*3]
+    uint8_t *aux_a = nullptr;      // [H*W*3]
+    uint8_t *aux_b = nullptr;      // [H*W*3]
+    BlobBuffers bb{};
+    const u64 *last_morph = nullptr;
+    ResultRec *res_dev = nullptr;  // [ring_depth+1][n]  (last slot: single-stage calls)
+    ResultRec *res_host = nullptr; // pinned, same shape
+    std::vector<hipEvent_t> ring_ev;
+    int ring_head = 0, ring_count = 0;
+
+    std::vector<int> nframes;      // per camera stream
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfStep> prof_steps;
+    size_t prof_used = 0;
+    oatgpu_profile prof_sum{};
+};
+
+static int fail(oatgpu_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), OATGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+extern "C" int oatgpu_abi_version(void) { return OATGPU_ABI_VERSION; }
+
+extern "C" int oatgpu_default_config(oatgpu_config *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    memset(c, 0, sizeof *c);
+    c->device = 0; c->n_streams = 1; c->rows = 0; c->cols = 0; c->ring_depth = 4;
+    // cv::createBackgroundSubtractorMOG2() defaults (bgfg_gaussmix2.cpp)
+    c->history = 500; c->nmixtures = 5; c->var_threshold = 16.f; c->background_ratio = 0.9f;
+    c->var_threshold_gen = 9.f; c->var_init = 15.f; c->var_min = 4.f; c->var_max = 75.f;
+    c->ct = 0.05f; c->tau = 0.5f; c->detect_shadows = 1; c->shadow_value = 127;
+    // HSVDetector.h:77-94, HSVDetector.cpp:42-43
+    c->h_lo = 0; c->h_hi = 256; c->s_lo = 0; c->s_hi = 256; c->v_lo = 0; c->v_hi = 256;
+    c->erode = 0; c->dilate = 10; c->min_area = 0.0; c->max_area = DBL_MAX;
+    return OATGPU_OK;
+}
+
+static int check_detector(oatgpu_ctx *c, const oatgpu_config &k)
+{
+    const int v[6] = { k.h_lo, k.h_hi, k.s_lo, k.s_hi, k.v_lo, k.v_hi };
+    for (int i = 0; i < 6; ++i)
+        if (v[i] < 0 || v[i] > 256)   // HSVDetector.cpp:87,98,109
+            return fail(c, OATGPU_E_INVALID, "threshold values should be between 0 and 256");
+    if (k.erode < 0 || k.dilate < 0) return fail(c, OATGPU_E_INVALID, "erode/dilate must be >= 0");
+    if (k.erode > 63 || k.dilate > 63)
+        return fail(c, OATGPU_E_INVALID, "erode/dilate kernel sizes above 63 are not supported");
+    if (!(k.min_area < k.max_area))   // HSVDetector.cpp:135
+        return fail(c, OATGPU_E_INVALID, "Max area should be larger than min area.");
+    return OATGPU_OK;
+}
+
+// cv::inRange's scalar-bound normalisation for 8U sources
+static void norm_range(int lo, int hi, int &l, int &h)
+{
+    if (lo > hi || lo > 255 || hi < 0) { l = 1; h = 0; return; }
+    l = lo < 0 ? 0 : lo;
+    h = hi > 255 ? 255 : hi;
+}
+static RangeParams range_of(const oatgpu_config &k)
+{
+    RangeParams r;
+    norm_range(k.h_lo, k.h_hi, r.lo[0], r.hi[0]);
+    norm_range(k.s_lo, k.s_hi, r.lo[1], r.hi[1]);
+    norm_range(k.v_lo, k.v_hi, r.lo[2], r.hi[2]);
+    return r;
+}
+static MogParams mogparams_of(const oatgpu_config &k)
+{
+    MogParams m;
+    m.Tb = k.var_threshold; m.TB = k.background_ratio; m.Tg = k.var_threshold_gen;
+    m.varInit = k.var_init; m.varMin = k.var_min; m.varMax = k.var_max; m.tau = k.tau;
+    m.nmix = k.nmixtures; m.detectShadows = k.detect_shadows; m.shadowVal = k.shadow_value;
+    return m;
+}
+
+static void free_all(oatgpu_ctx *c)
+{
+    if (!c) return;
+    hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
+    hipFree(c->bb.thr); hipFree(c->bb.tmp); hipFree(c->bb.morph); hipFree(c->bb.fin); hipFree(c->bb.trans);
+    hipFree(c->bb.carry); hipFree(c->bb.parent); hipFree(c->bb.acc); hipFree(c->bb.best);
+    hipFree(c->res_dev);
+    if (c->res_host) hipHostFree(c->res_host);
+    for (auto e : c->ring_ev) hipEventDestroy(e);
+    for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
+{
+    if (!cfg) { fail(nullptr, OATGPU_E_INVALID, "null config"); return nullptr; }
+    if (cfg->rows < 1 || cfg->cols < 1 || cfg->n_streams < 1 || cfg->ring_depth < 1) {
+        fail(nullptr, OATGPU_E_INVALID, "rows, cols, n_streams and ring_depth must be >= 1");
+        return nullptr;
+    }
+    if (cfg->nmixtures < 1 || cfg->nmixtures > kMaxMix) {
+        fail(nullptr, OATGPU_E_INVALID, "nmixtures must be in 1..5");
+        return nullptr;
+    }
+    if ((long long)cfg->rows * (((long long)cfg->cols + 63) / 64 * 64) > 0x7fff0000ll) {
+        fail(nullptr, OATGPU_E_INVALID, "frame too large");
+        return nullptr;
+    }
+    if (check_detector(nullptr, *cfg) != OATGPU_OK) return nullptr;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        fail(nullptr, OATGPU_E_NODEVICE, "no HIP device available");
+        return nullptr;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        fail(nullptr, OATGPU_E_INVALID, "device %d out of range (have %d)", cfg->device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        fail(nullptr, OATGPU_E_HIP, "hipSetDevice(%d) failed", cfg->device);
+        return nullptr;
+    }
+
+    oatgpu_ctx *c = new oatgpu_ctx();
+    c->cfg = *cfg;
+    Geom &g = c->g;
+    g.H = cfg->rows; g.W = cfg->cols; g.Wp = (cfg->cols + 63) / 64 * 64; g.words = g.Wp / 64;
+    g.P = g.H * g.Wp; g.Palloc = (g.P + 1023) / 1024 * 1024; g.n_streams = cfg->n_streams;
+    const size_t n = cfg->n_streams, npx = (size_t)g.H * g.W, PA = g.Palloc, NW = PA / 64;
+    c->nframes.assign(n, 0);
+
+    bool ok = true;
+    auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+    ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->own_stream = ok;
+    A((void **)&c->state, n * kMogPlanes * PA * sizeof(float));
+    A((void **)&c->nmodes, n * PA);
+    A((void **)&c->frames, n * npx * 3);
+    A((void **)&c->aux_a, npx * 3);
+    A((void **)&c->aux_b, npx * 3);
+    A((void **)&c->bb.thr, n * NW * 8);
+    A((void **)&c->bb.tmp, n * NW * 8);
+    A((void **)&c->bb.morph, n * NW * 8);
+    A((void **)&c->bb.fin, n * NW * 8);
+    A((void **)&c->bb.trans, n * NW * 8);
+    A((void **)&c->bb.carry, n * (size_t)g.H * g.words * sizeof(int));
+    A((void **)&c->bb.parent, n * PA * sizeof(int));
+    A((void **)&c->bb.acc, n * PA * 3 * sizeof(long long));
+    A((void **)&c->bb.best, n * 8);
+    const size_t slots = (size_t)cfg->ring_depth + 1;
+    A((void **)&c->res_dev, slots * n * sizeof(ResultRec));
+    if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec)) != hipSuccess) ok = false;
+    if (ok) {
+        c->ring_ev.resize(cfg->ring_depth);
+        for (auto &e : c->ring_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+    }
+    // the model's mode counters start at zero; everything else is written before it is read
+    if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb.thr, 0, n * NW * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+    if (!ok) {
+        fail(nullptr, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        free_all(c);
+        return nullptr;
+    }
+    c->last_morph = c->bb.thr;
+    return c;
+}
+
+extern "C" void oatgpu_destroy(oatgpu_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_all(c);
+}
+
+extern "C" const char *oatgpu_last_error(const oatgpu_ctx *c)
+{
+    return c ? c->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
+{
+    if (!c) return OATGPU_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return OATGPU_OK;
+}
+extern "C" void *oatgpu_get_stream(oatgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_set_detector(oatgpu_ctx *c, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
+                                   int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
+                                   double min_area, double max_area)
+{
+    if (!c) return OATGPU_E_INVALID;
+    oatgpu_config k = c->cfg;
+    k.h_lo = h_lo; k.h_hi = h_hi; k.s_lo = s_lo; k.s_hi = s_hi; k.v_lo = v_lo; k.v_hi = v_hi;
+    k.erode = erode; k.dilate = dilate; k.min_area = min_area; k.max_area = max_area;
+    int rc = check_detector(c, k);
+    if (rc) return rc;
+    c->cfg = k;
+    return OATGPU_OK;
+}
+
+// ---- BackgroundSubtractorMOG2Impl::apply prologue for one camera stream ----
+struct Rate { float alphaT, alpha1, prune; int fresh; };
+static Rate mog_begin(oatgpu_ctx *c, int s, double learningRate)
+{
+    Rate r;
+    int &nf = c->nframes[s];
+    const bool needToInitialize = nf == 0 || learningRate >= 1;
+    r.fresh = needToInitialize ? 1 : 0;
+    if (needToInitialize) nf = 0;
+    ++nf;
+    const int lim = 2 * nf < c->cfg.history ? 2 * nf : c->cfg.history;
+    learningRate = (learningRate >= 0 && nf > 1) ? learningRate : 1. / lim;
+    r.alphaT = (float)learningRate;
+    r.alpha1 = 1.f - r.alphaT;
+    r.prune = (float)(-learningRate * c->cfg.ct);   // product in double, as the reference
+    return r;
+}
+
+static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rate &r)
+{
+    MogLaunch a{};
+    a.frames = frames; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = c->bb.thr;
+    a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0;
+    a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
+    a.mp = mogparams_of(c->cfg);
+    a.rp = range_of(c->cfg);
+    return a;
+}
+
+static int check_stream_ix(oatgpu_ctx *c, int s)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (s < 0 || s >= c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "stream index %d out of range", s);
+    return OATGPU_OK;
+}
+
+static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask_out, uint8_t *bgr_out, double lr)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!bgr_in) return fail(c, OATGPU_E_INVALID, "null frame");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t npx = (size_t)c->g.H * c->g.W;
+    uint8_t *slot = c->frames + (size_t)s * npx * 3;
+    HIPCHK(c, hipMemcpyAsync(slot, bgr_in, npx * 3, hipMemcpyHostToDevice, c->stream));
+    const Rate r = mog_begin(c, s, lr);
+    MogLaunch a = mog_launch_base(c, c->frames, r);
+    a.out_base = s;
+    if (mask_out) a.out_mask = c->aux_a;
+    if (bgr_out) a.out_bgr = c->aux_b;
+    launch_mog_fused(c->g, a, s, 1, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, c->aux_a, npx, hipMemcpyDeviceToHost, c->stream));
+    if (bgr_out) HIPCHK(c, hipMemcpyAsync(bgr_out, c->aux_b, npx * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_mog_apply(oatgpu_ctx *c, int32_t s, const uint8_t *bgr_in, uint8_t *fgmask_out, double lr)
+{
+    if (!fgmask_out) return fail(c, OATGPU_E_INVALID, "null mask buffer");
+    return mog_single(c, s, bgr_in, fgmask_out, nullptr, lr);
+}
+
+extern "C" int oatgpu_mog_filter(oatgpu_ctx *c, int32_t s, const uint8_t *bgr_in, uint8_t *bgr_out, double lr)
+{
+    if (!bgr_out) return fail(c, OATGPU_E_INVALID, "null output frame");
+    return mog_single(c, s, bgr_in, nullptr, bgr_out, lr);
+}
+
+extern "C" int oatgpu_bgr2hsv(oatgpu_ctx *c, const uint8_t *bgr_in, uint8_t *hsv_out)
+{
+    if (!c || !bgr_in || !hsv_out) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t npx = (size_t)c->g.H * c->g.W;
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, bgr_in, npx * 3, hipMemcpyHostToDevice, c->stream));
+    launch_bgr2hsv(c->aux_a, c->aux_b, npx, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hsv_out, c->aux_b, npx * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+// contourMoments' epilogue (imgproc/moments.cpp) + siftContours' centroid
+// (DetectorFunc.cpp:54-62) on the exact integer sums.
+static void to_position(const ResultRec &r, oatgpu_position *o)
+{
+    memset(o, 0, sizeof *o);
+    o->first_pixel = -1;
+    if (!r.valid) return;
+    const double a00 = (double)r.a00, a10 = (double)r.a10, a01 = (double)r.a01;
+    double db1_2, db1_6;
+    if (a00 > 0) { db1_2 = 0.5; db1_6 = 0.16666666666666666666666666666667; }
+    else { db1_2 = -0.5; db1_6 = -0.16666666666666666666666666666667; }
+    const double m00 = a00 * db1_2, m10 = a10 * db1_6, m01 = a01 * db1_6;
+    o->valid = 1;
+    o->first_pixel = r.first_pixel;
+    o->x = m10 / m00;
+    o->y = m01 / m00;
+    o->area = m00;
+    o->a00 = r.a00; o->a10 = r.a10; o->a01 = r.a01;
+}
+
+// erode -> dilate -> blob for streams [s0, s0+n) starting from bb.thr; results to slot
+static int back_half(oatgpu_ctx *c, int s0, int n, int slot, hipEvent_t ev_mid)
+{
+    const Geom &g = c->g;
+    const u64 *src = c->bb.thr;
+    if (c->cfg.erode > 1) {
+        launch_morph(g, src, c->bb.tmp, c->cfg.erode, true, s0, n, c->stream);
+        src = c->bb.tmp;
+    }
+    if (c->cfg.dilate > 1) {
+        launch_morph(g, src, c->bb.morph, c->cfg.dilate, false, s0, n, c->stream);
+        src = c->bb.morph;
+    }
+    c->last_morph = src;
+    if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, c->stream));
+    ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
+    launch_blob(g, c->bb, src, c->cfg.min_area, c->cfg.max_area, rd, s0, n, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->res_host + (size_t)slot * c->cfg.n_streams + s0, rd + s0,
+                             (size_t)n * sizeof(ResultRec), hipMemcpyDeviceToHost, c->stream));
+    return OATGPU_OK;
+}
+
+static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, oatgpu_position *out)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const Geom &g = c->g;
+    const size_t npx = (size_t)g.H * g.W;
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, npx * channels, hipMemcpyHostToDevice, c->stream));
+    RangeParams rp = range_of(c->cfg);
+    launch_inrange_bits(g, c->aux_a, channels, rp, c->bb.thr + (size_t)s * (g.Palloc >> 6), c->stream);
+    const int slot = c->cfg.ring_depth;   // the extra slot
+    rc = back_half(c, s, 1, slot, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_detect_hsv(oatgpu_ctx *c, int32_t s, const uint8_t *hsv_in, oatgpu_position *out)
+{
+    return detect_single(c, s, hsv_in, 3, out);
+}
+extern "C" int oatgpu_detect_thresh(oatgpu_ctx *c, int32_t s, const uint8_t *grey_in, oatgpu_position *out)
+{
+    return detect_single(c, s, grey_in, 1, out);
+}
+
+// ------------------------------------------------------------ fused path ----
+
+static void prof_fold(oatgpu_ctx *c)
+{
+    if (!c->prof_used) return;
+    hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        float a = 0, b = 0, d = 0, t = 0;
+        ProfStep &p = c->prof_steps[i];
+        hipEventElapsedTime(&a, p.e[0], p.e[1]);
+        hipEventElapsedTime(&b, p.e[1], p.e[2]);
+        hipEventElapsedTime(&d, p.e[2], p.e[3]);
+        hipEventElapsedTime(&t, p.e[0], p.e[3]);
+        c->prof_sum.steps += 1;
+        c->prof_sum.mog_ms += a; c->prof_sum.morph_ms += b; c->prof_sum.blob_ms += d; c->prof_sum.total_ms += t;
+    }
+    c->prof_used = 0;
+}
+
+extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, double lr)
+{
+    if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int n = c->cfg.n_streams;
+    const int slot = (c->ring_head + c->ring_count) % c->cfg.ring_depth;
+
+    ProfStep *ps = nullptr;
+    if (c->prof) {
+        if (c->prof_used == c->prof_steps.size()) {
+            if (c->prof_steps.size() >= 1024) prof_fold(c);
+            else {
+                ProfStep p;
+                for (auto &e : p.e) HIPCHK(c, hipEventCreate(&e));
+                c->prof_steps.push_back(p);
+            }
+        }
+        ps = &c->prof_steps[c->prof_used++];
+        HIPCHK(c, hipEventRecord(ps->e[0], c->stream));
+    }
+
+    // every camera stream advances one frame; launches are batched while the
+    // streams share a learning-rate schedule (they do unless the single-stage
+    // calls were used unevenly)
+    std::vector<Rate> rates(n);
+    for (int s = 0; s < n; ++s) rates[s] = mog_begin(c, s, lr);
+    int s0 = 0;
+    while (s0 < n) {
+        int s1 = s0 + 1;
+        while (s1 < n && memcmp(&rates[s1], &rates[s0], sizeof(Rate)) == 0) ++s1;
+        MogLaunch a = mog_launch_base(c, (const uint8_t *)frames_dev, rates[s0]);
+        launch_mog_fused(c->g, a, s0, s1 - s0, c->stream);
+        s0 = s1;
+    }
+    HIPCHK(c, hipGetLastError());
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[1], c->stream));
+    int rc = back_half(c, 0, n, slot, ps ? ps->e[2] : nullptr);
+    if (rc) return rc;
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[3], c->stream));
+    HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
+    c->ring_count++;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
+{
+    if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->ring_count == 0) return fail(c, OATGPU_E_RING_EMPTY, "nothing outstanding");
+    const int slot = c->ring_head;
+    HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+    const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
+    for (int s = 0; s < c->cfg.n_streams; ++s) to_position(r[s], &out[s]);
+    c->ring_head = (c->ring_head + 1) % c->cfg.ring_depth;
+    c->ring_count--;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_track_outstanding(const oatgpu_ctx *c) { return c ? c->ring_count : 0; }
+
+extern "C" int oatgpu_track_batch_dev(oatgpu_ctx *c, const void *frames_dev, double lr, oatgpu_position *out)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "track_batch while enqueued results are outstanding");
+    int rc = oatgpu_track_enqueue_dev(c, frames_dev, lr);
+    if (rc) return rc;
+    return oatgpu_track_collect(c, out);
+}
+
+extern "C" int oatgpu_track_batch(oatgpu_ctx *c, const uint8_t *const *frames_host, int32_t n, double lr,
+                                  oatgpu_position *out)
+{
+    if (!c || !frames_host || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (n != c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "expected %d frames, got %d", c->cfg.n_streams, n);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t fb = (size_t)c->g.H * c->g.W * 3;
+    for (int s = 0; s < n; ++s) {
+        if (!frames_host[s]) return fail(c, OATGPU_E_INVALID, "null frame %d", s);
+        HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)s * fb, frames_host[s], fb, hipMemcpyHostToDevice, c->stream));
+    }
+    return oatgpu_track_batch_dev(c, c->frames, lr, out);
+}
+
+// ------------------------------------------------------------------ taps ----
+
+extern "C" int oatgpu_read_mask(oatgpu_ctx *c, int32_t s, int32_t which, uint8_t *out)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!out) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 *base = which == OATGPU_TAP_THRESHOLD ? c->bb.thr
+                    : which == OATGPU_TAP_MORPH ? c->last_morph
+                    : which == OATGPU_TAP_FINAL ? c->bb.fin : nullptr;
+    if (!base) return fail(c, OATGPU_E_INVALID, "unknown tap %d", which);
+    const size_t npx = (size_t)c->g.H * c->g.W;
+    launch_unpack_bits(c->g, base + (size_t)s * (c->g.Palloc >> 6), c->aux_b, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, npx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_used, float *weight, float *variance,
+                                    float *mean, int32_t *nframes)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const Geom &g = c->g;
+    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures;
+    uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_mu, npx));
+    HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
+    HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
+    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * 12));
+    launch_state_export(g, c->state + (size_t)s * kMogPlanes * g.Palloc, c->nmodes + (size_t)s * g.Palloc, (int)k,
+                        d_mu, d_w, d_v, d_m, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && modes_used) e = hipMemcpyAsync(modes_used, d_mu, npx, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && weight) e = hipMemcpyAsync(weight, d_w, npx * k * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && variance) e = hipMemcpyAsync(variance, d_v, npx * k * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && mean) e = hipMemcpyAsync(mean, d_m, npx * k * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_mu); hipFree(d_w); hipFree(d_v); hipFree(d_m);
+    if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state export failed: %s", hipGetErrorString(e));
+    if (nframes) *nframes = c->nframes[s];
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *modes_used, const float *weight,
+                                    const float *variance, const float *mean, int32_t nframes)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!modes_used || !weight || !variance || !mean || nframes < 0)
+        return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const Geom &g = c->g;
+    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures;
+    uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_mu, npx));
+    HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
+    HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
+    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * 12));
+    hipError_t e = hipMemcpyAsync(d_mu, modes_used, npx, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, weight, npx * k * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_v, variance, npx * k * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m, mean, npx * k * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_state_import(g, c->state + (size_t)s * kMogPlanes * g.Palloc, c->nmodes + (size_t)s * g.Palloc, (int)k,
+                            d_mu, d_w, d_v, d_m, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_mu); hipFree(d_w); hipFree(d_v); hipFree(d_m);
+    if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state import failed: %s", hipGetErrorString(e));
+    c->nframes[s] = nframes;
+    return OATGPU_OK;
+}
+
+// ---------------------------------------------------------- measurement ----
+
+extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (!on) prof_fold(c);
+    c->prof = on != 0;
+    return OATGPU_OK;
+}
+extern "C" int oatgpu_profile_read(oatgpu_ctx *c, oatgpu_profile *out)
+{
+    if (!c || !out) return OATGPU_E_INVALID;
+    prof_fold(c);
+    *out = c->prof_sum;
+    return OATGPU_OK;
+}
+extern "C" int oatgpu_profile_reset(oatgpu_ctx *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    prof_fold(c);
+    c->prof_sum = oatgpu_profile{};
+    return OATGPU_OK;
+}

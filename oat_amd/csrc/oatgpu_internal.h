@@ -1,0 +1,110 @@
+// oatgpu_internal.h -- device-side layout contract shared by the kernel TUs and
+// the C-ABI TU.  Not installed; the public surface is include/oatgpu.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oatgpu {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------
+// Geometry.  Every per-pixel device array of one camera stream lives in a
+// PADDED index space: row pitch Wp = 64*ceil(W/64) pixels, so a 64-bit mask
+// word never straddles two image rows.  p = y*Wp + x.  (For 640/1920/3840
+// wide frames Wp == W and p is the plain raster index.)
+// Arrays are allocated for Palloc = 1024*ceil(H*Wp/1024) entries so that the
+// MOG kernel's 1024-pixel blocks need no tail handling on state planes.
+// ---------------------------------------------------------------------------
+struct Geom {
+    int H, W, Wp;        // rows, cols, padded pitch
+    int words;           // Wp / 64 mask words per row
+    int P;               // H * Wp
+    int Palloc;          // P rounded up to 1024
+    int n_streams;
+};
+
+// MOG2 model layout in HBM (per stream): 25 fp32 planes + one u8 plane.
+//   plane 0..4   weight[k]
+//   plane 5..9   variance[k]
+//   plane 10+3k+c  mean[k][c]
+// Inside a plane the 256 pixels one wavefront owns are stored lane-interleaved:
+//   pixel p = base + 64*j + lane   (base multiple of 256, j in 0..3)
+//   slot    = base + 4*lane + j
+// so one float4 load per lane fetches that lane's four pixels (16 B/lane,
+// 1 KiB per wave instruction) and pixels {base+64j .. base+64j+63} -- one mask
+// word -- sit in component j of the 64 lanes.
+constexpr int kMogPlanes = 25;
+constexpr int kMaxMix = 5;
+
+__host__ __device__ inline int mog_slot(int p)
+{
+    int base = p & ~255, r = p & 255;
+    return base + 4 * (r & 63) + (r >> 6);
+}
+
+struct MogParams {
+    float Tb, TB, Tg, varInit, varMin, varMax, tau;
+    int nmix;
+    int detectShadows;
+    int shadowVal;
+};
+
+// inRange bounds after cv::inRange's normalisation: lo > hi encodes "empty".
+struct RangeParams {
+    int lo[3], hi[3];
+};
+
+struct MogLaunch {
+    const uint8_t *frames;   // [n][H*W*3] packed BGR
+    float *state;            // [n][25][Palloc]
+    uint8_t *nmodes;         // [n][Palloc]  (same lane-interleaved slots)
+    u64 *thr_bits;           // [n][Palloc/64] or nullptr
+    uint8_t *out_bgr;        // [n][H*W*3] masked frame or nullptr
+    uint8_t *out_mask;       // [n][H*W] {0,127,255} or nullptr
+    int out_base;            // out_bgr / out_mask are indexed by (stream - out_base)
+    float alphaT, alpha1, prune;
+    int fresh;               // 1: model is (re)initialised this frame -> no modes
+    MogParams mp;
+    RangeParams rp;
+};
+
+// --- kernels_mog.hip ---
+void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st);
+void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
+// 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.
+void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
+                         u64 *bits, hipStream_t st);
+void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st);
+// model checkpoint: logical (OpenCV AoS) <-> device planes
+void launch_state_export(const Geom &g, const float *state, const uint8_t *nmodes, int nmix,
+                         uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st);
+void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix,
+                         const uint8_t *modes_used, const float *weight, const float *variance,
+                         const float *mean, hipStream_t st);
+
+// --- kernels_blob.hip ---
+struct BlobBuffers {
+    u64 *thr;        // [n][Palloc/64] inRange output
+    u64 *tmp;        // [n][Palloc/64] morphology ping
+    u64 *morph;      // [n][Palloc/64] after erode/dilate
+    u64 *fin;        // [n][Palloc/64] after 1-px frame zeroing
+    u64 *trans;      // [n][Palloc/64] run-start (transition) bits
+    int *carry;      // [n][H*words]   start x of the run entering each word
+    int *parent;     // [n][Palloc]    union-find over run heads (sparse)
+    long long *acc;  // [n][Palloc][3] Green sums per root (sparse)
+    u64 *best;       // [n]            packed selection key
+};
+struct ResultRec {   // device-side result, one per stream per step
+    long long a00, a10, a01;
+    int first_pixel;
+    int valid;
+};
+
+void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode, int first_stream,
+                  int n_streams, hipStream_t st);
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, double min_area,
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st);
+
+}  // namespace oatgpu

@@ -1,0 +1,115 @@
+"""ctypes binding of include/oatgpu.h (one declaration per exported symbol)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "liboatgpu.so")
+
+
+class OatGpuError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"oatgpu error {code}: {text}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("n_streams", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("ring_depth", C.c_int32),
+        ("history", C.c_int32), ("nmixtures", C.c_int32),
+        ("var_threshold", C.c_float), ("background_ratio", C.c_float), ("var_threshold_gen", C.c_float),
+        ("var_init", C.c_float), ("var_min", C.c_float), ("var_max", C.c_float), ("ct", C.c_float),
+        ("tau", C.c_float), ("detect_shadows", C.c_int32), ("shadow_value", C.c_int32),
+        ("h_lo", C.c_int32), ("h_hi", C.c_int32), ("s_lo", C.c_int32), ("s_hi", C.c_int32),
+        ("v_lo", C.c_int32), ("v_hi", C.c_int32), ("erode", C.c_int32), ("dilate", C.c_int32),
+        ("min_area", C.c_double), ("max_area", C.c_double),
+    ]
+
+
+class Position(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("first_pixel", C.c_int32), ("x", C.c_double), ("y", C.c_double),
+                ("area", C.c_double), ("a00", C.c_int64), ("a10", C.c_int64), ("a01", C.c_int64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("mog_ms", C.c_double), ("morph_ms", C.c_double),
+                ("blob_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+E_RING_FULL = -4
+E_RING_EMPTY = -5
+TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
+
+_u8p = C.POINTER(C.c_uint8)
+_fp = C.POINTER(C.c_float)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/oatgpu.h line by line
+SIGNATURES = {
+    "oatgpu_abi_version": (C.c_int, []),
+    "oatgpu_default_config": (C.c_int, [C.POINTER(Config)]),
+    "oatgpu_create": (_ctx, [C.POINTER(Config)]),
+    "oatgpu_destroy": (None, [_ctx]),
+    "oatgpu_last_error": (C.c_char_p, [_ctx]),
+    "oatgpu_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "oatgpu_get_stream": (C.c_void_p, [_ctx]),
+    "oatgpu_synchronize": (C.c_int, [_ctx]),
+    "oatgpu_set_detector": (C.c_int, [_ctx] + [C.c_int32] * 8 + [C.c_double, C.c_double]),
+    "oatgpu_mog_apply": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
+    "oatgpu_mog_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
+    "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
+    "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
+    "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
+    "oatgpu_track_batch": (C.c_int, [_ctx, C.POINTER(_u8p), C.c_int32, C.c_double, C.POINTER(Position)]),
+    "oatgpu_track_batch_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double, C.POINTER(Position)]),
+    "oatgpu_track_enqueue_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double]),
+    "oatgpu_track_collect": (C.c_int, [_ctx, C.POINTER(Position)]),
+    "oatgpu_track_outstanding": (C.c_int, [_ctx]),
+    "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),
+    "oatgpu_mog_get_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.POINTER(C.c_int32)]),
+    "oatgpu_mog_set_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.c_int32]),
+    "oatgpu_profile_enable": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_profile_read": (C.c_int, [_ctx, C.POINTER(Profile)]),
+    "oatgpu_profile_reset": (C.c_int, [_ctx]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads liboatgpu.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension has not been built "
+            "(run `make` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oatgpu_abi_version() != 1:
+        raise ImportError("liboatgpu.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != 0:
+        msg = lib.oatgpu_last_error(ctx)
+        raise OatGpuError(rc, msg.decode() if msg else "")
+
+
+def u8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def f32(a):
+    return a.ctypes.data_as(_fp)

@@ -1,0 +1,75 @@
+"""CPU tests: liboatgpu.so loads and exports exactly what include/oatgpu.h declares
+(no compute calls -- there is no GPU here), and the binding's struct layouts match."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(os.path.join(ROOT, "oat_amd", "lib", "liboatgpu.so")):
+        subprocess.check_call(["make", "-s", "-j4", "-C", ROOT, "oat_amd/lib/liboatgpu.so"])
+    from oat_amd import ffi
+    return ffi.load()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "oatgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(oatgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from oat_amd import ffi
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/oatgpu.h but not exported"
+    assert sorted(ffi.SIGNATURES) == names
+
+
+def test_abi_version_and_default_config(lib):
+    from oat_amd import ffi
+    assert lib.oatgpu_abi_version() == 1
+    cfg = ffi.Config()
+    assert lib.oatgpu_default_config(C.byref(cfg)) == 0
+    # cv::createBackgroundSubtractorMOG2() defaults + HSVDetector.h:77-94
+    assert (cfg.history, cfg.nmixtures, cfg.detect_shadows, cfg.shadow_value) == (500, 5, 1, 127)
+    assert (cfg.var_threshold, cfg.var_threshold_gen, cfg.var_init, cfg.var_min, cfg.var_max) == (16, 9, 15, 4, 75)
+    assert abs(cfg.background_ratio - 0.9) < 1e-7 and abs(cfg.ct - 0.05) < 1e-8 and cfg.tau == 0.5
+    assert (cfg.h_lo, cfg.h_hi, cfg.s_lo, cfg.s_hi, cfg.v_lo, cfg.v_hi) == (0, 256, 0, 256, 0, 256)
+    assert (cfg.erode, cfg.dilate, cfg.min_area) == (0, 10, 0.0) and cfg.max_area > 1e308
+
+
+def test_struct_sizes_match_the_header(lib, tmp_path):
+    from oat_amd import ffi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "oatgpu.h"\nint main(){printf("%zu %zu %zu\\n",'
+                   'sizeof(oatgpu_config),sizeof(oatgpu_position),sizeof(oatgpu_profile));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(ffi.Config), C.sizeof(ffi.Position), C.sizeof(ffi.Profile)]
+
+
+def test_create_without_gpu_fails_loudly_not_silently(lib):
+    """No CPU fallback: with no HIP device the product refuses to run."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import oat_amd
+    with pytest.raises(oat_amd.OatGpuError):
+        oat_amd.HotPath(48, 64)
+
+
+def test_hsv_table_integer_formula_equals_cvround():
+    """The kernel builds RGB2HSV_b's tables with (2n+i)/(2i); check against cvRound(n/i)."""
+    import numpy as np
+    for i in range(1, 256):
+        assert (2 * (255 << 12) + i) // (2 * i) == int(np.rint((255 << 12) / (1.0 * i)))
+        assert (2 * ((180 << 12) // 6) + i) // (2 * i) == int(np.rint((180 << 12) / (6.0 * i)))

@@ -1,0 +1,406 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI (oat_amd -> liboatgpu.so), against the CPU oracle on the same inputs.
+
+Bar: bit-exact for every byte/integer result (masks, HSV, model counters, Green
+sums) AND for the fp32 MOG2 model (same operation order, no FMA contraction);
+centroids within 1e-4 px (BASELINE.json north_star) -- they are expected to be
+identical because both sides finish the same exact int64 sums in double.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CENTROID_TOL = 1e-4     # px, from BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def A():
+    import oat_amd
+    return oat_amd
+
+
+def _same_detection(got, want, tag=""):
+    assert got.position_valid == want["valid"], (tag, got, want)
+    assert got.area == want["area"], (tag, got, want)
+    if want["valid"]:
+        assert (got.a00, got.a10, got.a01) == (want["a00"], want["a10"], want["a01"]), (tag, got, want)
+        assert got.first_pixel == want["first_pixel"], (tag, got, want)
+        assert abs(got.x - want["x"]) <= CENTROID_TOL and abs(got.y - want["y"]) <= CENTROID_TOL, (tag, got, want)
+        assert got.x == want["x"] and got.y == want["y"], (tag, got, want)
+
+
+def _same_state(gpu_state, ora_state, tag=""):
+    nm_g, w_g, v_g, m_g, _ = gpu_state
+    nm_o, w_o, v_o, m_o = ora_state
+    assert (nm_g == nm_o).all(), tag
+    k = w_o.shape[1]
+    live = np.arange(k)[None, :] < nm_o[:, None]
+    assert (w_g[live] == w_o[live]).all(), tag
+    assert (v_g[live] == v_o[live]).all(), tag
+    assert (m_g[live] == m_o[live]).all(), tag
+
+
+# ------------------------------------------------------------------ colour --
+
+def test_bgr2hsv_exhaustive_256cubed(A):
+    """All 16.7M colours (computed, not stored)."""
+    n = 4096
+    idx = np.arange(n * n, dtype=np.uint32)
+    bgr = np.stack([(idx & 255), (idx >> 8) & 255, (idx >> 16) & 255], -1).astype(np.uint8).reshape(n, n, 3)
+    got = A.ColorConvert(n, n).filter(bgr)
+    assert (got == O.bgr2hsv(bgr)).all()
+
+
+def test_bgr2hsv_known_answers(A, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "hsv_kat.json")))
+    bgr = np.zeros((1, 64, 3), np.uint8)
+    bgr[0, :len(g["bgr"])] = g["bgr"]
+    got = A.ColorConvert(1, 64).filter(bgr)
+    assert got[0, :len(g["bgr"])].tolist() == g["hsv"]
+
+
+# --------------------------------------------------------------------- MOG2 --
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 101), (5, 3), (1, 1), (33, 256)])
+@pytest.mark.parametrize("rate", [0.0, 0.01, 0.3])
+def test_mog2_mask_and_model_parity(A, shape, rate):
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 1000 + cols + int(rate * 100))
+    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=rate)
+    o = O.Mog2(rows, cols, 3)
+    base = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
+    alt = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
+    for t in range(120):
+        sel = rng.random((rows, cols, 1)) < 0.25
+        f = np.where(sel, alt, base) + rng.integers(-12, 13, (rows, cols, 3))
+        if t % 17 == 3:
+            f[:] = rng.integers(0, 256, (rows, cols, 3))
+        if t % 23 == 5:
+            f[rows // 2:] = 0
+        f = np.clip(f, 0, 255).astype(np.uint8)
+        mg = g.apply(f)
+        mo = o.apply(f, rate)
+        assert (mg == mo).all(), (shape, rate, t, int((mg != mo).sum()))
+        if t % 20 == 19 or t < 3:
+            _same_state(g.mog_state(), o.state(), (shape, rate, t))
+
+
+def test_mog2_single_pixel_traces(A, golden_dir):
+    """The hand-independent float32 traces of tests/golden/mog2_trace.json, on the GPU."""
+    for tr in json.load(open(os.path.join(golden_dir, "mog2_trace.json"))):
+        g = A.BackgroundSubtractorMOG(1, 1)
+        for t, (px, want) in enumerate(zip(tr["pixels"], tr["frames"])):
+            mask = g.apply(np.array(px, np.uint8).reshape(1, 1, 3), learning_rate=tr["rate"])
+            nm, w, v, mu, _ = g.mog_state()
+            k = want["nmodes"]
+            assert int(mask[0, 0]) == want["mask"], (tr["name"], t)
+            assert int(nm[0]) == k, (tr["name"], t)
+            assert w[0, :k].tolist() == [np.float32(x) for x in want["weight"]], (tr["name"], t)
+            assert v[0, :k].tolist() == [np.float32(x) for x in want["variance"]], (tr["name"], t)
+            assert mu[0, :k].tolist() == [[np.float32(c) for c in r] for r in want["mean"]], (tr["name"], t)
+
+
+def test_mog_filter_frame1_and_frozen_model(A):
+    """BackgroundSubtractorMOG::filter with Oat's default -a 0."""
+    rng = np.random.default_rng(3)
+    rows, cols = 40, 70
+    f1 = rng.integers(1, 256, (rows, cols, 3), dtype=np.uint8)
+    f1[0, 0] = 0
+    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=0.0)
+    o = O.Mog2(rows, cols, 3)
+    out = g.filter(f1.copy())
+    assert (out == f1).all()                       # first output frame is the unmodified input
+    o.filter(f1, 0.0)
+    for t in range(5):
+        f = np.clip(f1.astype(int) + rng.integers(-14, 15, f1.shape), 0, 255).astype(np.uint8)
+        want, _ = o.filter(f, 0.0)
+        got = g.filter(f.copy())
+        assert (got == want).all()
+    _same_state(g.mog_state(), o.state())
+
+
+def test_mog_state_roundtrip_and_resume(A):
+    rng = np.random.default_rng(5)
+    rows, cols = 30, 90
+    a = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=0.02)
+    frames = [rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8) for _ in range(12)]
+    for f in frames[:6]:
+        a.apply(f)
+    nm, w, v, m, nf = a.mog_state()
+    b = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=0.02)
+    live = np.arange(w.shape[1])[None, :] < nm[:, None]
+    w = np.where(live, w, 0); v = np.where(live, v, 0); m = np.where(live[..., None], m, 0)
+    b.set_mog_state(nm, w, v, m, nf)
+    for f in frames[6:]:
+        assert (a.apply(f) == b.apply(f)).all()
+
+
+# --------------------------------------------------------------- morphology --
+
+@pytest.mark.parametrize("shape", [(40, 64), (35, 130), (9, 7), (64, 200)])
+def test_erode_dilate_parity(A, shape):
+    rows, cols = shape
+    rng = np.random.default_rng(rows + cols)
+    for e, d in [(0, 0), (0, 10), (3, 7), (7, 7), (2, 2), (13, 1), (1, 13), (5, 0), (10, 3)]:
+        img = (rng.random((rows, cols)) < rng.uniform(0.3, 0.97)).astype(np.uint8) * 255
+        det = A.SimpleThreshold(rows, cols, thresh=(1, 256), erode=e, dilate=d)
+        det.detectPosition(img)
+        want = img
+        if e:
+            want = O.erode(want, e)
+        if d:
+            want = O.dilate(want, d)
+        got = det.read_mask(1)
+        assert (got == want).all(), (shape, e, d)
+
+
+def test_morph_impulses_golden(A, golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "morph_impulse.json"))):
+        img = np.zeros((c["rows"], c["cols"]), np.uint8)
+        img[c["y0"], c["x0"]] = 255
+        want = np.zeros_like(img)
+        want[c["y_lo"]:c["y_hi"] + 1, c["x_lo"]:c["x_hi"] + 1] = 255
+        det = A.SimpleThreshold(c["rows"], c["cols"], thresh=(1, 256), erode=0, dilate=c["k"])
+        det.detectPosition(img)
+        assert (det.read_mask(1) == want).all(), c
+        det = A.SimpleThreshold(c["rows"], c["cols"], thresh=(1, 256), erode=c["k"], dilate=0)
+        det.detectPosition(255 - img)
+        assert (det.read_mask(1) == 255 - want).all(), c
+
+
+# ------------------------------------------------------------ blob analysis --
+
+def test_contour_known_answers(A, golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "contours.json"))):
+        img = np.array(c["img"], np.uint8) * 255
+        det = A.SimpleThreshold(img.shape[0], img.shape[1], thresh=(1, 256),
+                                area=(c.get("min_area", 0.0), c.get("max_area", float(np.finfo(np.float64).max))))
+        p = det.detectPosition(img)
+        assert p.position_valid == c["valid"], (c["name"], p)
+        assert p.area == c["area"], (c["name"], p)
+        if c["valid"]:
+            assert p.x == c["x"] and p.y == c["y"], (c["name"], p)
+
+
+def _blob_images(n, seed, max_hw=90):
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        h, w = int(rng.integers(1, max_hw)), int(rng.integers(1, max_hw * 2))
+        img = (rng.random((h, w)) < rng.uniform(0.15, 0.9)).astype(np.uint8) * 255
+        if it % 3 == 0 and h > 3 and w > 3:
+            img = O.dilate(img, int(rng.integers(2, 5)))
+        if it % 5 == 0:
+            img = O.erode(img, 2)
+        if it % 7 == 0 and h > 8 and w > 8:
+            img[:] = 0
+            step = int(rng.integers(2, 4))
+            for k in range(0, min(h, w) // 2 - 1, step):
+                img[k + 1:h - k - 1, k + 1:w - k - 1] = 255 if (k // step) % 2 == 0 else 0
+            img ^= ((rng.random((h, w)) < 0.04) * 255).astype(np.uint8)
+        yield img, rng
+
+
+def test_blob_parity_random_images(A):
+    """Noise, dilated noise, nested rings: sequential OpenCV-3.1 border following
+    (oracle) vs the run-based union-find + crack sums on the GPU."""
+    cache = {}
+    for img, rng in _blob_images(400, 21):
+        lo = float(rng.choice([0.0, 0.0, 2.0, 10.0]))
+        hi = float(rng.choice([np.finfo(np.float64).max, 60.0, 400.0]))
+        key = img.shape
+        if key not in cache:
+            cache[key] = A.SimpleThreshold(img.shape[0], img.shape[1], thresh=(1, 256))
+        det = cache[key]
+        det._set(min_area=lo, max_area=hi)
+        got = det.detectPosition(img)
+        want = O.sift_contours(img, lo, hi)
+        _same_detection(got, want, (img.shape, lo, hi))
+        if len(cache) > 64:
+            cache.clear()
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (300, 1000), (1080, 1920)])
+def test_blob_parity_large_noise(A, shape):
+    """Union-find stress: ~50% noise gives hundreds of thousands of runs and deep merges."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows)
+    det = A.SimpleThreshold(rows, cols, thresh=(1, 256))
+    for dens, dil in [(0.5, 0), (0.42, 0), (0.6, 2), (0.08, 9), (0.995, 0)]:
+        img = (rng.random((rows, cols)) < dens).astype(np.uint8) * 255
+        det._set(dilate=dil)
+        got = det.detectPosition(img)
+        thr = O.dilate(img, dil) if dil else img
+        assert (det.read_mask(1) == thr).all()
+        _same_detection(got, O.sift_contours(thr), (shape, dens, dil))
+
+
+def test_all_pass_default_is_one_full_frame_contour(A):
+    """posidet hsv defaults (HSVDetector.h:86-94): everything passes, dilate 10."""
+    rows, cols = 120, 200
+    hsv = np.random.default_rng(0).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    det = A.HSVDetector(rows, cols)
+    got = det.detectPosition(hsv)
+    want, thr = O.detect_hsv(hsv, O.hsv_params())
+    _same_detection(got, want)
+    assert got.area == (rows - 3) * (cols - 3)      # frame ring zeroed: (W-2) x (H-2) pixels
+    assert (det.read_mask(1) == thr).all()
+
+
+def test_detect_hsv_parity(A):
+    rng = np.random.default_rng(8)
+    rows, cols = 96, 160
+    for it in range(25):
+        hsv = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        # a few coherent blobs so that windows select something
+        for _ in range(4):
+            y, x = int(rng.integers(0, rows - 20)), int(rng.integers(0, cols - 30))
+            hsv[y:y + int(rng.integers(3, 20)), x:x + int(rng.integers(3, 30))] = (int(rng.integers(90, 120)), 220, 200)
+        h = sorted(rng.integers(0, 257, 2).tolist()) if it % 4 else [90, 125]
+        s = sorted(rng.integers(0, 257, 2).tolist()) if it % 3 else [0, 256]
+        v = sorted(rng.integers(0, 257, 2).tolist()) if it % 5 else [1, 256]
+        e, d = int(rng.integers(0, 6)), int(rng.integers(0, 12))
+        area = (float(rng.choice([0, 5, 20])), float(rng.choice([1e5, 300.0])))
+        det = A.HSVDetector(rows, cols, h_thresh=h, s_thresh=s, v_thresh=v, erode=e, dilate=d, area=area)
+        got = det.detectPosition(hsv)
+        p = O.hsv_params(h_lo=h[0], h_hi=h[1], s_lo=s[0], s_hi=s[1], v_lo=v[0], v_hi=v[1], erode=e, dilate=d,
+                         min_area=area[0], max_area=area[1])
+        want, thr = O.detect_hsv(hsv, p)
+        assert (det.read_mask(1) == thr).all(), it
+        _same_detection(got, want, it)
+
+
+def test_position_keeps_stale_xy_when_nothing_found(A):
+    """siftContours leaves position.x/y untouched when no contour qualifies (DetectorFunc.cpp:46-62)."""
+    det = A.SimpleThreshold(20, 20, thresh=(1, 256))
+    img = np.zeros((20, 20), np.uint8); img[5:9, 5:9] = 255
+    pos = det.detectPosition(img)
+    assert pos.position_valid and (pos.x, pos.y) == (6.5, 6.5)
+    pos = det.detectPosition(np.zeros((20, 20), np.uint8), pos)
+    assert not pos.position_valid and (pos.x, pos.y) == (6.5, 6.5) and pos.area == 0.0
+
+
+# -------------------------------------------------------------- fused chain --
+
+def _chain_oracles(rows, cols, n):
+    return [O.Mog2(rows, cols, 3) for _ in range(n)]
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.01])
+def test_hot_path_chain_parity_640x480(A, rate):
+    """BASELINE config 1 shape, 3 batched streams, 60 frames: threshold masks pixel-exact,
+    positions identical to the reference CPU chain (oracle)."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols, n = 480, 640, 3
+    win = disc_hsv_window()
+    hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=rate, erode=3, dilate=7, area=(20.0, 1e5), **win)
+    p = O.hsv_params(h_lo=win["h_thresh"][0], h_hi=win["h_thresh"][1], s_lo=win["s_thresh"][0],
+                     s_hi=win["s_thresh"][1], v_lo=win["v_thresh"][0], v_hi=win["v_thresh"][1],
+                     erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    streams = [SyntheticStream(rows, cols, s, n_discs=1 + s % 3) for s in range(n)]
+    oracles = _chain_oracles(rows, cols, n)
+    found = 0
+    for t in range(60):
+        frames = [st.frame(t, with_discs=(t > 0)) for st in streams]
+        got = hp.track(frames)
+        for s in range(n):
+            want, thr = O.chain_step(oracles[s], frames[s], rate, p)
+            if t % 10 == 0 or t < 3:
+                assert (hp.read_mask(1, s) == thr).all(), (t, s)
+            _same_detection(got[s], want, (t, s))
+            found += got[s].position_valid
+    assert found > 100          # the discs really are tracked
+    for s in range(n):
+        _same_state(hp.mog_state(s), oracles[s].state(), s)
+
+
+@pytest.mark.parametrize("shape,frames", [((1080, 1920), 4), ((2160, 3840), 3)])
+def test_hot_path_full_size_parity(A, shape, frames):
+    """BASELINE configs 2 and 5 shapes against the oracle directly (a few frames each)."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols = shape
+    win = disc_hsv_window()
+    hp = A.HotPath(rows, cols, n_streams=1, adaptation_coeff=0.01, erode=7, dilate=7, area=(20.0, 1e5), **win)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=7, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    st = SyntheticStream(rows, cols, 0, n_discs=2)
+    orc = O.Mog2(rows, cols, 3)
+    for t in range(frames):
+        f = st.frame(t, with_discs=(t > 0))
+        got = hp.track([f])[0]
+        want, thr = O.chain_step(orc, f, 0.01, p, nthreads=8)
+        assert (hp.read_mask(1) == thr).all(), t
+        _same_detection(got, want, t)
+    _same_state(hp.mog_state(), orc.state())
+
+
+def test_hot_path_size_independent_properties(A):
+    """4K properties that need no oracle: (i) with a frozen model the same frame gives the
+    same answer twice (idempotence); (ii) translating the blob by (dx,dy) translates the
+    centroid by exactly (dx,dy) and keeps the area (linearity of the Green sums)."""
+    rows, cols = 2160, 3840
+    hp = A.HotPath(rows, cols, n_streams=1, adaptation_coeff=0.0, erode=3, dilate=7, area=(20.0, 1e6),
+                   h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    bg = np.full((rows, cols, 3), 120, np.uint8)
+    hp.track([bg])                                   # frame 1 learns the background
+
+    def with_blob(x0, y0):
+        f = bg.copy()
+        yy, xx = np.mgrid[0:81, 0:121]
+        m = ((xx - 60) / 60.0) ** 2 + ((yy - 40) / 40.0) ** 2 <= 1.0
+        f[y0:y0 + 81, x0:x0 + 121][m] = (255, 64, 0)
+        return f
+    a1 = hp.track([with_blob(500, 700)])[0]
+    a2 = hp.track([with_blob(500, 700)])[0]
+    b = hp.track([with_blob(500 + 2613, 700 + 1111)])[0]
+    assert a1.position_valid and a1 == a2
+    assert b.area == a1.area and b.a00 == a1.a00
+    assert abs((b.x - a1.x) - 2613) <= CENTROID_TOL and abs((b.y - a1.y) - 1111) <= CENTROID_TOL
+
+
+def test_enqueue_collect_order_and_ring_limits(A):
+    import torch
+    from oat_amd import ffi
+    rows, cols, n = 64, 128, 2
+    hp = A.HotPath(rows, cols, n_streams=n, ring_depth=3, adaptation_coeff=0.0, dilate=0, erode=0,
+                   v_thresh=(200, 256), area=(0.5, 1e9))
+    dev = torch.device("cuda:0")
+
+    def frames(k):
+        f = np.zeros((n, rows, cols, 3), np.uint8)
+        if k:
+            f[0, 10:10 + k + 2, 10:14] = 255      # area grows with k
+            f[1, 20:24, 30:30 + k + 2] = 255
+        return f
+    bufs = [torch.from_numpy(frames(k)).to(dev) for k in range(5)]
+    torch.cuda.synchronize()
+    hp.track_dev(bufs[0].data_ptr())
+    for k in (1, 2, 3):
+        hp.enqueue_dev(bufs[k].data_ptr())
+    with pytest.raises(A.OatGpuError) as ei:
+        hp.enqueue_dev(bufs[4].data_ptr())
+    assert ei.value.code == ffi.E_RING_FULL
+    for k in (1, 2, 3):
+        r = hp.collect()
+        assert r[0].position_valid and r[0].area == (k + 1) * 3.0
+        assert r[1].position_valid and r[1].area == 3.0 * (k + 1)
+    with pytest.raises(A.OatGpuError) as ei:
+        hp.collect()
+    assert ei.value.code == ffi.E_RING_EMPTY
+
+
+def test_error_behaviour(A):
+    with pytest.raises(A.OatGpuError):
+        A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135
+    with pytest.raises(A.OatGpuError):
+        A.HSVDetector(10, 10, h_thresh=(0, 300))        # HSVDetector.cpp:87
+    with pytest.raises(ValueError):
+        A.BackgroundSubtractorMOG(10, 10, adaptation_coeff=1.5)
+    d = A.HSVDetector(10, 10)
+    with pytest.raises(A.OatGpuError):
+        d.detectPosition(np.zeros((10, 10, 3), np.uint8), stream=3)
