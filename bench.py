@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused hot path (mog + hsv + erode/dilate + blob) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one frame for every camera stream a rank owns, through the whole
+fused chain (MOG2 update, setTo, BGR2HSV, inRange, erode, dilate, labelling,
+contour sums, selection, result D2H).  Input frames are synthetic, uchar3, and
+already resident in HBM when the timed region starts.  Streams are independent,
+so N > 1 shards streams over ranks with no data-path collective ("weak"
+scaling: per-GPU work fixed); rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+    1080p1   1 x 1920x1080 stream per GPU            (configs[1], the default)
+    1080p16  16 x 1920x1080 streams batched per GPU  (configs[2]; configs[3] at N=8 is 8/GPU)
+    1080p8   8 x 1920x1080 per GPU                   (configs[3] shard)
+    4k1      1 x 3840x2160 per GPU, erode 7 dilate 7 (configs[4])
+    vga1     1 x 640x480                             (configs[0] shape)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PIXEL = 205           # 3 B BGR + 101 B model read + 101 B model write
+
+WORKLOADS = {
+    "1080p1": dict(rows=1080, cols=1920, streams=1, erode=3, dilate=7),
+    "1080p8": dict(rows=1080, cols=1920, streams=8, erode=3, dilate=7),
+    "1080p16": dict(rows=1080, cols=1920, streams=16, erode=3, dilate=7),
+    "4k1": dict(rows=2160, cols=3840, streams=1, erode=7, dilate=7),
+    "vga1": dict(rows=480, cols=640, streams=1, erode=3, dilate=7),
+}
+ALPHA = 0.01
+AREA = (20.0, 1e5)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_hotpath(wl, device, ring_depth):
+    import oat_amd
+    from oat_amd.synth import disc_hsv_window
+    return oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=wl["streams"], adaptation_coeff=ALPHA,
+                           erode=wl["erode"], dilate=wl["dilate"], area=AREA, device=device,
+                           ring_depth=ring_depth, **disc_hsv_window())
+
+
+def oracle_params(wl):
+    import oracle_lib as O
+    return O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=wl["erode"],
+                        dilate=wl["dilate"], min_area=AREA[0], max_area=AREA[1])
+
+
+def parity_gate(wl, device, frames_seq):
+    """masks pixel-exact and centroids identical vs the oracle, on a short fresh run
+    of stream 0's frames (the oracle only CHECKS here; it is never the thing measured)."""
+    import oracle_lib as O
+    import oat_amd
+    from oat_amd.synth import disc_hsv_window
+    hp = oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=1, adaptation_coeff=ALPHA, erode=wl["erode"],
+                         dilate=wl["dilate"], area=AREA, device=device, **disc_hsv_window())
+    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+    p = oracle_params(wl)
+    for t, f in enumerate(frames_seq):
+        got = hp.track([f])[0]
+        want, thr = O.chain_step(orc, f, ALPHA, p, nthreads=os.cpu_count() or 1)
+        if not (hp.read_mask(1) == thr).all():
+            return f"mask mismatch at frame {t}"
+        if got.position_valid != want["valid"]:
+            return f"valid mismatch at frame {t}"
+        if want["valid"] and (abs(got.x - want["x"]) > 1e-4 or abs(got.y - want["y"]) > 1e-4):
+            return f"centroid mismatch at frame {t}"
+    hp.close()
+    return "ok"
+
+
+def cpu_baseline(wl, frames_seq, budget_s=12.0):
+    """The oracle (a port of the reference's CPU chain) timed on this host, bounded sample."""
+    import oracle_lib as O
+    ncores = os.cpu_count() or 1
+    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+    p = oracle_params(wl)
+    O.chain_step(orc, frames_seq[0], ALPHA, p, nthreads=ncores)      # frame 1 (model init), untimed
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        O.chain_step(orc, frames_seq[(n + 1) % len(frames_seq)], ALPHA, p, nthreads=ncores)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    return dict(value=n / el, unit="frames/s", cores=ncores, kind="port",
+                sample=f"{n} frames of one {wl['cols']}x{wl['rows']} stream, {el:.1f} s, oracle chain "
+                       f"(MOG2 rows over {ncores} threads; hsv/inRange/morphology/contours 1 thread)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
+    ap.add_argument("--pool", type=int, default=8, help="distinct frame sets resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    wl = WORKLOADS[args.workload]
+    rows, cols, ns = wl["rows"], wl["cols"], wl["streams"]
+    K, W = args.steps, args.warmup
+    ring = 8
+
+    # ---- synthetic input pool, uploaded once (this rank's streams: global ids rank*ns ..) ----
+    from oat_amd.synth import SyntheticStream
+    streams = [SyntheticStream(rows, cols, rank * ns + s, n_discs=2) for s in range(ns)]
+    pool_host = [np.stack([st.frame(t, with_discs=t > 0) for st in streams]) for t in range(args.pool)]
+    pool = [torch.from_numpy(p).to(dev) for p in pool_host]
+    torch.cuda.synchronize()
+
+    parity = "skipped"
+    if rank == 0 and not args.no_parity:
+        parity = parity_gate(wl, local_rank, [p[0] for p in pool_host[:4]])
+        log("parity gate:", parity)
+
+    hp = make_hotpath(wl, local_rank, ring)
+
+    def barrier():
+        hp.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    positions = []
+
+    def run(nsteps, keep=False):
+        for i in range(nsteps):
+            if hp.outstanding() == ring:
+                r = hp.collect()
+                if keep:
+                    positions.append(r)
+            hp.enqueue_dev(pool[(i + 1) % len(pool)].data_ptr())
+        while hp.outstanding():
+            r = hp.collect()
+            if keep:
+                positions.append(r)
+
+    # frame 1 initialises the models with the disc-free frame, then warm-up
+    hp.track_dev(pool[0].data_ptr())
+    run(W)
+    hp.profile(True)
+    hp.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    run(K, keep=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = hp.profile_read()
+    hp.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        found = torch.tensor([sum(p.position_valid for r in positions for p in r)], dtype=torch.int64, device=dev)
+        dist.all_reduce(found, op=dist.ReduceOp.SUM)
+        n_found = int(found.item())
+    else:
+        n_found = sum(p.position_valid for r in positions for p in r)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_streams = ns * world
+    fps = total_streams * K / elapsed
+    px_per_launch = rows * cols * ns
+    mog_ms = prof["mog_ms"] / max(prof["steps"], 1)
+    achieved = BYTES_PER_PIXEL * px_per_launch / (mog_ms * 1e-3) / 1e9 if mog_ms > 0 else 0.0
+    line = {
+        "metric": "frames/sec/GPU (1080p & 4K) mog+hsv+ccl fused; % HBM roofline",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{ns} x {cols}x{rows} uchar3 stream(s) per GPU, MOG2(5 mixtures, lr {ALPHA}) + HSV + "
+                               f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
+                   "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
+                   "learning_rate": ALPHA, "parallelism": f"streams sharded, {world} rank(s)"},
+        "fps_per_gpu": fps / world,
+        "hbm_roofline_frac_whole_step": BYTES_PER_PIXEL * px_per_launch / (elapsed / K) / 1e9 / HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "k_mog_fused", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "bytes_per_launch": BYTES_PER_PIXEL * px_per_launch, "avg_launch_ms": mog_ms},
+        "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
+                     "blob": prof["blob_ms"] / max(prof["steps"], 1),
+                     "gpu_total": prof["total_ms"] / max(prof["steps"], 1)},
+        "positions_found": n_found,
+        "positions_expected": total_streams * K,
+        "parity": parity,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(wl, [p[0] for p in pool_host])
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If torch is
+    # imported AFTER this library has pulled in /opt/rocm's runtime, torch finds no GPU; imported
+    # first, both share torch's copy (same SONAME).  So when torch is installed, load it first.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("OATGPU_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(
