@@ -105,13 +105,54 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
                        f"(MOG2 rows over {ncores} threads; hsv/inRange/morphology/contours 1 thread)")
 
 
+def make_pool_device(rows, cols, ns, nframes, rank, dev):
+    """[nframes] tensors of shape (ns, rows, cols, 3) uint8 on `dev`."""
+    from oat_amd.synth import DISC_BGR
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x0A7 + rank)
+    yy = torch.arange(rows, device=dev, dtype=torch.float32).view(rows, 1)
+    xx = torch.arange(cols, device=dev, dtype=torch.float32).view(1, cols)
+    base = 110 + 30 * (xx / max(cols - 1, 1)) + 20 * (yy / max(rows - 1, 1))
+    base = torch.stack([base, base + 6, base - 5], -1).to(torch.int16)            # (rows, cols, 3)
+    flick = ((torch.arange(rows * cols, device=dev) % 64) == 17).view(rows, cols)
+    rmin = max(4, min(rows, cols) // 40)
+    cpu_rng = np.random.default_rng(0x0A7 + rank)
+    discs = []
+    for s in range(ns):
+        ds = []
+        for d in range(2):
+            r = int(cpu_rng.integers(rmin, 2 * rmin + 1))
+            ds.append(dict(r=r, col=DISC_BGR[d], ax=(cols / 2 - r - 24) * (0.55 + 0.15 * d),
+                           ay=(rows / 2 - r - 24) * (0.5 + 0.2 * d),
+                           fx=0.013 * (1 + d) + 0.002 * (s % 7), fy=0.017 * (1 + 0.5 * d) + 0.001 * (s % 5),
+                           px=cpu_rng.uniform(0, 6.28), py=cpu_rng.uniform(0, 6.28)))
+        discs.append(ds)
+    pool = []
+    for t in range(nframes):
+        f = base.unsqueeze(0) + torch.randint(-6, 7, (ns, rows, cols, 3), device=dev, dtype=torch.int16, generator=g)
+        f[:, flick] += 60 if (t & 1) else -50
+        f = f.clamp_(0, 255).to(torch.uint8)
+        if t > 0:                                   # frame 0 (model initialisation) has no discs
+            for s in range(ns):
+                for d in discs[s]:
+                    cx = int(round(cols / 2 + d["ax"] * np.sin(d["fx"] * 9 * t + d["px"])))
+                    cy = int(round(rows / 2 + d["ay"] * np.sin(d["fy"] * 9 * t + d["py"])))
+                    r = d["r"]
+                    y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, rows), max(cx - r, 0), min(cx + r + 1, cols)
+                    m = ((xx[:, x0:x1] - cx) ** 2 + (yy[y0:y1] - cy) ** 2) <= r * r
+                    sub = f[s, y0:y1, x0:x1]
+                    sub[m] = torch.tensor(d["col"], device=dev, dtype=torch.uint8)
+        pool.append(f.contiguous())
+    return pool
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
-    ap.add_argument("--pool", type=int, default=8, help="distinct frame sets resident in HBM")
+    ap.add_argument("--pool", type=int, default=48, help="distinct frame sets resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -133,12 +174,13 @@ def main():
     K, W = args.steps, args.warmup
     ring = 8
 
-    # ---- synthetic input pool, uploaded once (this rank's streams: global ids rank*ns ..) ----
-    from oat_amd.synth import SyntheticStream
-    streams = [SyntheticStream(rows, cols, rank * ns + s, n_discs=2) for s in range(ns)]
-    pool_host = [np.stack([st.frame(t, with_discs=t > 0) for st in streams]) for t in range(args.pool)]
-    pool = [torch.from_numpy(p).to(dev) for p in pool_host]
+    # ---- synthetic input pool, generated on the device once (this rank's streams have global
+    # ids rank*ns ..): gradient + fresh +-6 noise per frame, every 64th pixel flickering, two
+    # saturated discs per stream on Lissajous paths.  The pool is long enough that
+    # a disc revisits a pixel too rarely to be learnt as background.
+    pool = make_pool_device(rows, cols, ns, args.pool, rank, dev)
     torch.cuda.synchronize()
+    pool_host = [p[0:1].cpu().numpy() for p in pool[:8]]     # stream 0, for the parity gate / CPU baseline
 
     parity = "skipped"
     if rank == 0 and not args.no_parity:

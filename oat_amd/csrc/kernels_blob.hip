@@ -88,19 +88,43 @@ void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode,
                        is_erode ? 1 : 0, first_stream);
 }
 
+// dilation of word (y, w) straight from the pre-dilation mask (same window rule as k_morph)
+__device__ __forceinline__ u64 dilate_word(const Geom &g, const u64 *src, int y, int w, int k)
+{
+    const int a = k / 2;
+    u64 ap = 0, ac = 0, an = 0;
+    for (int j = 0; j < k; ++j) {
+        const int yy = y - a + j;
+        if (yy < 0 || yy >= g.H) continue;
+        const u64 *row = src + (size_t)yy * g.words;
+        if (w > 0) ap |= row[w - 1];
+        ac |= row[w];
+        if (w + 1 < g.words) an |= row[w + 1];
+    }
+    u64 out = 0;
+    for (int j = 0; j < k; ++j) {
+        const int o = j - a;
+        out |= (o == 0) ? ac : (o > 0) ? ((ac >> o) | (an << (64 - o))) : ((ac << (-o)) | (ap >> (64 + o)));
+    }
+    return out & valid_bits(g, w);
+}
+
 // ------------------------------------------------------------- row scan ------
 // One wavefront per image row, one lane per mask word (rows wider than 4096 px
-// loop in chunks of 64 words).  Writes the final mask (image frame zeroed, as
-// cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start x of
-// the run entering every word, and initialises the union-find at run heads.
-__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, BlobBuffers b, int first_stream)
+// loop in chunks of 64 words).  Applies the dilation (dil_k > 1) on the fly,
+// writes the final mask (image frame zeroed, as cvStartFindContours does in
+// OpenCV 3.1), the run-start bits T, the start x of the run entering every
+// word, and initialises the union-find at run heads.
+__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int dil_k, BlobBuffers b,
+                                                 int first_stream)
 {
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (y >= g.H) return;
     const int s = first_stream + blockIdx.y;
     const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
-    const u64 *src = src_all + woff;
+    const u64 *src_img = src_all + (size_t)s * (g.Palloc >> 6);
+    u64 *morph = b.morph + woff;
     u64 *fin = b.fin + woff;
     u64 *trans = b.trans + woff;
     int *carry = b.carry + (size_t)s * g.H * g.words + (size_t)y * g.words;
@@ -117,8 +141,15 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, Blo
         const int w = c0 + lane;
         const bool active = w < g.words;
         u64 F = 0;
+        if (active && dil_k > 1) {
+            F = dilate_word(g, src_img, y, w, dil_k);
+            morph[w] = F;                            // the reference's threshold_frame_ (parity tap)
+        } else if (active) {
+            F = src_img[(size_t)y * g.words + w];
+        }
+        if (frame_row) F = 0;
         if (active && !frame_row) {
-            F = src[w] & valid_bits(g, w);
+            F &= valid_bits(g, w);
             if (w == 0) F &= ~1ull;
             if (w == (lastx >> 6)) F &= ~(1ull << (lastx & 63));
         }
@@ -140,13 +171,6 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, Blo
             fin[w] = F;
             trans[w] = T;
             carry[w] = cin;
-            u64 tt = T;
-            while (tt) {
-                const int i = lsb64(tt);
-                tt &= tt - 1;
-                const int head = y * g.Wp + w * 64 + i;
-                parent[head] = head;
-            }
         }
         // carry state into the next chunk (all lanes agree)
         if (nz) {
@@ -155,6 +179,28 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, Blo
             chunk_carry = (c0 + hl) * 64 + msb64(Th);
         }
         chunk_prevbit = __shfl(F, 63) >> 63;
+    }
+
+    // Union-find initialisation at run heads.  Column 0 and column W-1 are background in every
+    // row (zeroed frame) and vertically 4-connected, so the first and the last run of every row
+    // belong to the OUTSIDE component: hang them under root 0 right away -- on ordinary frames
+    // this removes the H-long merge chain of full-width background runs.  Foreground run heads
+    // get their Green accumulators cleared here.
+    const int last_start = chunk_carry;          // start x of the row's last run
+    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+    for (int c0 = 0; c0 < g.words; c0 += 64) {
+        const int w = c0 + lane;
+        if (w >= g.words) continue;
+        u64 tt = trans[w];                       // written by this very lane above
+        const u64 F = fin[w];
+        while (tt) {
+            const int i = lsb64(tt);
+            tt &= tt - 1;
+            const int sx = w * 64 + i;
+            const int head = y * g.Wp + sx;
+            parent[head] = (sx == 0 || sx == last_start) ? 0 : head;
+            if ((F >> i) & 1ull) { acc[(size_t)head * 3] = 0; acc[(size_t)head * 3 + 1] = 0; acc[(size_t)head * 3 + 2] = 0; }
+        }
     }
 }
 
@@ -271,26 +317,21 @@ __global__ __launch_bounds__(256) void k_merge(Geom g, BlobBuffers b, int first_
     }
 }
 
-// One thread = one word: every run head points straight at its root; roots of
-// foreground components get their accumulators cleared.
+// One thread = one word: every run head points straight at its root.
 __global__ __launch_bounds__(256) void k_flatten(Geom g, BlobBuffers b, int first_stream)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= g.H * g.words) return;
     const int s = first_stream + blockIdx.y;
     const int y = t / g.words, w = t - y * g.words;
-    const size_t soff = (size_t)s * (g.Palloc >> 6);
-    const u64 F = b.fin[soff + t];
-    u64 T = b.trans[soff + t];
+    u64 T = b.trans[(size_t)s * (g.Palloc >> 6) + t];
     int *parent = b.parent + (size_t)s * g.Palloc;
-    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
     while (T) {
         const int i = lsb64(T);
         T &= T - 1;
         const int h = y * g.Wp + w * 64 + i;
         const int r = uf_find(parent, h);
         if (r != h) __hip_atomic_store(parent + h, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if ((F >> i) & 1ull) { acc[(size_t)h * 3] = 0; acc[(size_t)h * 3 + 1] = 0; acc[(size_t)h * 3 + 2] = 0; }
     }
 }
 
@@ -380,56 +421,68 @@ __global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_
 
 // One thread = one word: every foreground root offers (|a00|, first pixel) as a
 // packed key; atomicMax keeps the largest area, ties -> the later first pixel
-// (the reference walks its reversed list with a strict '>').
+// (the reference walks its reversed list with a strict '>').  The last
+// workgroup of a stream to finish (arrival counter, agent-scope release /
+// acquire) turns the winning key into the stream's result record, written
+// straight into host-mapped memory.
 __global__ __launch_bounds__(256) void k_select(Geom g, BlobBuffers b, double min_area, double max_area,
-                                                int first_stream)
+                                                ResultRec *results, int first_stream)
 {
+    __shared__ int is_last;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.H * g.words) return;
     const int s = first_stream + blockIdx.y;
-    const int y = t / g.words, w = t - y * g.words;
-    const size_t soff = (size_t)s * (g.Palloc >> 6);
-    u64 heads = b.trans[soff + t] & b.fin[soff + t];
-    const int *parent = b.parent + (size_t)s * g.Palloc;
-    const long long *acc = b.acc + (size_t)s * g.Palloc * 3;
-    while (heads) {
-        const int i = lsb64(heads);
-        heads &= heads - 1;
-        const int h = y * g.Wp + w * 64 + i;
-        if (parent[h] != h) continue;
-        const long long a00 = acc[(size_t)h * 3];
-        if (a00 == 0) continue;
-        const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
-        const double area = (double)mag * 0.5;        // m00 = a00 * (+-0.5), exact
-        if (area >= min_area && area < max_area)
-            atomicMax((unsigned long long *)&b.best[s], (mag << 32) | (u64)(unsigned)h);
+    if (t < g.H * g.words) {
+        const int y = t / g.words, w = t - y * g.words;
+        const size_t soff = (size_t)s * (g.Palloc >> 6);
+        u64 heads = b.trans[soff + t] & b.fin[soff + t];
+        const int *parent = b.parent + (size_t)s * g.Palloc;
+        const long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+        while (heads) {
+            const int i = lsb64(heads);
+            heads &= heads - 1;
+            const int h = y * g.Wp + w * 64 + i;
+            if (parent[h] != h) continue;
+            const long long a00 = acc[(size_t)h * 3];
+            if (a00 == 0) continue;
+            const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
+            const double area = (double)mag * 0.5;        // m00 = a00 * (+-0.5), exact
+            if (area >= min_area && area < max_area)
+                atomicMax((unsigned long long *)&b.best[s], (mag << 32) | (u64)(unsigned)h);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(&b.done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == gridDim.x - 1) ? 1 : 0;
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const u64 key = __hip_atomic_load((unsigned long long *)&b.best[s], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            ResultRec r;
+            r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
+            if (key) {
+                const int h = (int)(key & 0xffffffffull);
+                const long long *acc = b.acc + ((size_t)s * g.Palloc + h) * 3;
+                r.a00 = acc[0]; r.a10 = acc[1]; r.a01 = acc[2];
+                const int y = h / g.Wp, x = h - y * g.Wp;
+                r.first_pixel = y * g.W + x;
+                r.valid = 1;
+            }
+            results[s] = r;
+            __hip_atomic_store(&b.done[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
-__global__ void k_finish(Geom g, BlobBuffers b, ResultRec *results, int first_stream, int n_streams)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_streams) return;
-    const int s = first_stream + i;
-    const u64 key = b.best[s];
-    ResultRec r;
-    r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
-    if (key) {
-        const int h = (int)(key & 0xffffffffull);
-        const long long *acc = b.acc + ((size_t)s * g.Palloc + h) * 3;
-        r.a00 = acc[0]; r.a10 = acc[1]; r.a01 = acc[2];
-        const int y = h / g.Wp, x = h - y * g.Wp;
-        r.first_pixel = y * g.W + x;
-        r.valid = 1;
-    }
-    results[s] = r;
-}
-
-void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, double min_area, double max_area,
-                 ResultRec *results, int first_stream, int n_streams, hipStream_t st)
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int dil_k, double min_area,
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st)
 {
     const int nw = g.H * g.words;
-    hipLaunchKernelGGL(k_rowscan, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, b, first_stream);
+    hipLaunchKernelGGL(k_rowscan, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, dil_k, b,
+                       first_stream);
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);
@@ -438,9 +491,7 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, doubl
         hipLaunchKernelGGL(k_green, dim3(((g.H - 2) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);
     hipLaunchKernelGGL(k_select, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, min_area, max_area,
-                       first_stream);
-    hipLaunchKernelGGL(k_finish, dim3((n_streams + 63) / 64), dim3(64), 0, st, g, b, results, first_stream,
-                       n_streams);
+                       results, first_stream);
 }
 
 }  // namespace oatgpu

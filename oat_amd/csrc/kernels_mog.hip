@@ -18,6 +18,11 @@
 //     unrolled, statically indexed mode loops (no scratch).
 //   * BGR->HSV uses the same integer tables as RGB2HSV_b, built once per block
 //     in LDS.
+//   * the model is sparse in practice (most pixels keep 1-2 of the 5 modes, and
+//     a frame changes only the matched mode's mean/variance): each lane loads
+//     only the planes of modes it has (exec-masked 16-byte loads; planes no lane
+//     of the wave needs are skipped outright) and writes back only planes whose
+//     bits changed.  The state in HBM stays bit-identical to updating all of it.
 #include "oatgpu_internal.h"
 
 namespace oatgpu {
@@ -28,8 +33,9 @@ struct PxModel {
     float m[kMaxMix][3];
 };
 
-__device__ __forceinline__ void swap_up(PxModel &s, int i)   // exchange modes i and i-1
+__device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // exchange modes i and i-1
 {
+    dvm |= (3u << (i - 1));
     float t;
     t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
     t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
@@ -39,8 +45,11 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i)   // exchange modes i
 
 // MOG2Invoker's per-pixel body (OpenCV 3.1.0 bgfg_gaussmix2.cpp) on a register
 // resident mixture.  Returns the foreground-mask value {0, shadowVal, 255}.
+// dvm: bit k set when mode k's variance/mean registers were written; wchg: weights may differ
+// from what was loaded (false only when alpha == 0 and the renormalisation was by exactly 1).
 __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, float x1, float x2,
-                                          const MogParams &P, float alphaT, float alpha1, float prune)
+                                          const MogParams &P, float alphaT, float alpha1, float prune,
+                                          unsigned &dvm, bool &wchg)
 {
     bool background = false, fits = false;
     int nmodes = nmodes_io;
@@ -70,6 +79,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
                     varnew = varnew > P.varMin ? varnew : P.varMin;
                     varnew = varnew < P.varMax ? varnew : P.varMax;
                     s.v[mode] = varnew;
+                    dvm |= (1u << mode);
                     // The reference bubbles the OLD weight up and then stores the new one
                     // into the final slot; carrying the new weight along is the same state.
                     s.w[mode] = weight;
@@ -78,7 +88,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
                     for (int i = mode; i > 0; --i) {
                         if (moving) {
                             if (weight < s.w[i - 1]) moving = false;
-                            else swap_up(s, i);
+                            else swap_up(s, i, dvm);
                         }
                     }
                 }
@@ -94,6 +104,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
 
     // renormalise
     const float inv = 1.f / total;
+    wchg = (alphaT > 0.f) || (inv != 1.f);
 #pragma unroll
     for (int mode = 0; mode < kMaxMix; ++mode)
         if (mode < nmodes) s.w[mode] *= inv;
@@ -106,6 +117,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
         for (int i = 0; i < kMaxMix; ++i) {
             if (!first && i < nmodes - 1) s.w[i] *= alpha1;
             if (i == mode) {
+                dvm |= (1u << i);
                 s.w[i] = first ? 1.f : alphaT;
                 s.v[i] = P.varInit;
                 s.m[i][0] = x0; s.m[i][1] = x1; s.m[i][2] = x2;
@@ -116,7 +128,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
         for (int i = kMaxMix - 1; i > 0; --i) {
             if (moving && i <= nmodes - 1) {
                 if (alphaT < s.w[i - 1]) moving = false;
-                else swap_up(s, i);
+                else swap_up(s, i, dvm);
             }
         }
     }
@@ -201,29 +213,32 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
     float *st = a.state + (size_t)s * kMogPlanes * g.Palloc + base + 4 * lane;
     uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + 4 * lane;
 
-    // ---- load the mixture of this lane's four pixels: 25 x 16 B ----
+    // ---- load the mixture of this lane's four pixels: up to 25 x 16 B, only live modes ----
     float W[kMaxMix][4], V[kMaxMix][4], M[kMaxMix][3][4];
-    int nmodes[4];
+    int nmodes[4] = {0, 0, 0, 0};
     if (!a.fresh) {
+        const uchar4 n4 = *(const uchar4 *)nm;
+        nmodes[0] = n4.x; nmodes[1] = n4.y; nmodes[2] = n4.z; nmodes[3] = n4.w;
+    }
+    const int nold0 = nmodes[0], nold1 = nmodes[1], nold2 = nmodes[2], nold3 = nmodes[3];
+    const int nmax_old = max(max(nold0, nold1), max(nold2, nold3));
 #pragma unroll
-        for (int k = 0; k < kMaxMix; ++k) {
+    for (int k = 0; k < kMaxMix; ++k) {
+        if (k < nmax_old) {
             *(float4 *)W[k] = *(const float4 *)(st + (size_t)k * g.Palloc);
             *(float4 *)V[k] = *(const float4 *)(st + (size_t)(5 + k) * g.Palloc);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 *(float4 *)M[k][c] = *(const float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc);
-        }
-        const uchar4 n4 = *(const uchar4 *)nm;
-        nmodes[0] = n4.x; nmodes[1] = n4.y; nmodes[2] = n4.z; nmodes[3] = n4.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < kMaxMix; ++k)
+        } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 W[k][j] = 0.f; V[k][j] = 0.f; M[k][0][j] = 0.f; M[k][1][j] = 0.f; M[k][2][j] = 0.f;
             }
-        nmodes[0] = nmodes[1] = nmodes[2] = nmodes[3] = 0;
+        }
     }
+    unsigned dvm = 0;           // modes whose variance/mean changed for any of the four pixels
+    bool wchg = false;          // weights changed for any of the four pixels
 
     u64 words[4];
 #pragma unroll
@@ -244,8 +259,11 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         }
         int n = nmodes[j];
         int mask = 0;
-        if (valid)
-            mask = mog2_pixel(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune);
+        if (valid) {
+            bool wc = false;
+            mask = mog2_pixel(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune, dvm, wc);
+            wchg |= wc;
+        }
         nmodes[j] = n;
 #pragma unroll
         for (int k = 0; k < kMaxMix; ++k) {
@@ -266,16 +284,22 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         words[j] = __ballot(thr);
     }
 
-    // ---- store the mixture back ----
+    // ---- store back only what changed (values not stored are bit-identical in HBM) ----
+    const int nmax_new = max(max(nmodes[0], nmodes[1]), max(nmodes[2], nmodes[3]));
+    const int nlive = max(nmax_old, nmax_new);
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
-        *(float4 *)(st + (size_t)k * g.Palloc) = *(const float4 *)W[k];
-        *(float4 *)(st + (size_t)(5 + k) * g.Palloc) = *(const float4 *)V[k];
+        if (wchg && k < nlive)
+            *(float4 *)(st + (size_t)k * g.Palloc) = *(const float4 *)W[k];
+        if ((dvm >> k) & 1u) {
+            *(float4 *)(st + (size_t)(5 + k) * g.Palloc) = *(const float4 *)V[k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            *(float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc) = *(const float4 *)M[k][c];
+            for (int c = 0; c < 3; ++c)
+                *(float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc) = *(const float4 *)M[k][c];
+        }
     }
-    *(uchar4 *)nm = make_uchar4((uint8_t)nmodes[0], (uint8_t)nmodes[1], (uint8_t)nmodes[2], (uint8_t)nmodes[3]);
+    if (a.fresh || nmodes[0] != nold0 || nmodes[1] != nold1 || nmodes[2] != nold2 || nmodes[3] != nold3)
+        *(uchar4 *)nm = make_uchar4((uint8_t)nmodes[0], (uint8_t)nmodes[1], (uint8_t)nmodes[2], (uint8_t)nmodes[3]);
 
     if (a.thr_bits && lane < 4) {
         const u64 wsel = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];

@@ -19,13 +19,18 @@ using namespace oatgpu;
 
 static thread_local std::string g_last_error;
 
-struct ProfStep { hipEvent_t e[4]; };
+struct ProfStep { hipEvent_t e[5]; };   // A: K1 begin/end; B: back-half begin, after erode, end
 
 struct oatgpu_ctx {
     oatgpu_config cfg;
     Geom g;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // stream A: uploads + the fused per-pixel kernel
     bool own_stream = false;
+    hipStream_t stream_b = nullptr; // stream B: morphology + blob analysis of the PREVIOUS frame, overlapped
+    hipEvent_t ev_k1[2] = {nullptr, nullptr};    // K1 of parity q finished (thr[q] is ready)
+    hipEvent_t ev_back[2] = {nullptr, nullptr};  // back half of parity q finished (thr[q] may be rewritten)
+    bool back_pending[2] = {false, false};
+    unsigned long long frame_no = 0;
     std::string err;
 
     // device memory
@@ -36,8 +41,8 @@ struct oatgpu_ctx {
     uint8_t *aux_b = nullptr;      // [H*W*3]
     BlobBuffers bb{};
     const u64 *last_morph = nullptr;
-    ResultRec *res_dev = nullptr;  // [ring_depth+1][n]  (last slot: single-stage calls)
-    ResultRec *res_host = nullptr; // pinned, same shape
+    ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
+    ResultRec *res_dev = nullptr;  // device alias of res_host: kernels store results straight to the host
     std::vector<hipEvent_t> ring_ev;
     int ring_head = 0, ring_count = 0;
 
@@ -130,9 +135,13 @@ static void free_all(oatgpu_ctx *c)
     if (!c) return;
     hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb.thr); hipFree(c->bb.tmp); hipFree(c->bb.morph); hipFree(c->bb.fin); hipFree(c->bb.trans);
-    hipFree(c->bb.carry); hipFree(c->bb.parent); hipFree(c->bb.acc); hipFree(c->bb.best);
-    hipFree(c->res_dev);
+    hipFree(c->bb.carry); hipFree(c->bb.parent); hipFree(c->bb.acc); hipFree(c->bb.best); hipFree(c->bb.done);
     if (c->res_host) hipHostFree(c->res_host);
+    for (int q = 0; q < 2; ++q) {
+        if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
+        if (c->ev_back[q]) hipEventDestroy(c->ev_back[q]);
+    }
+    if (c->stream_b) hipStreamDestroy(c->stream_b);
     for (auto e : c->ring_ev) hipEventDestroy(e);
     for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -182,12 +191,22 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
     ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     c->own_stream = ok;
+    {   // stream B carries short latency-bound kernels that must slip in between the big
+        // bandwidth-bound launches of stream A: give it the highest priority
+        int least = 0, greatest = 0;
+        if (ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+        ok = ok && hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, greatest) == hipSuccess;
+    }
+    for (int q = 0; q < 2 && ok; ++q) {
+        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_back[q], hipEventDisableTiming) == hipSuccess;
+    }
     A((void **)&c->state, n * kMogPlanes * PA * sizeof(float));
     A((void **)&c->nmodes, n * PA);
     A((void **)&c->frames, n * npx * 3);
     A((void **)&c->aux_a, npx * 3);
     A((void **)&c->aux_b, npx * 3);
-    A((void **)&c->bb.thr, n * NW * 8);
+    A((void **)&c->bb.thr, 2 * n * NW * 8);
     A((void **)&c->bb.tmp, n * NW * 8);
     A((void **)&c->bb.morph, n * NW * 8);
     A((void **)&c->bb.fin, n * NW * 8);
@@ -196,9 +215,11 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     A((void **)&c->bb.parent, n * PA * sizeof(int));
     A((void **)&c->bb.acc, n * PA * 3 * sizeof(long long));
     A((void **)&c->bb.best, n * 8);
+    A((void **)&c->bb.done, n * sizeof(unsigned));
     const size_t slots = (size_t)cfg->ring_depth + 1;
-    A((void **)&c->res_dev, slots * n * sizeof(ResultRec));
-    if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec)) != hipSuccess) ok = false;
+    if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
+        ok = false;
+    if (ok && hipHostGetDevicePointer((void **)&c->res_dev, c->res_host, 0) != hipSuccess) ok = false;
     if (ok) {
         c->ring_ev.resize(cfg->ring_depth);
         for (auto &e : c->ring_ev)
@@ -206,7 +227,9 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     }
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb.thr, 0, n * NW * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb.thr, 0, 2 * n * NW * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
         fail(nullptr, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -222,6 +245,7 @@ extern "C" void oatgpu_destroy(oatgpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream_b) hipStreamSynchronize(c->stream_b);
     free_all(c);
 }
 
@@ -234,6 +258,7 @@ extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_b));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
@@ -244,6 +269,7 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_b));
     return OATGPU_OK;
 }
 
@@ -279,10 +305,25 @@ static Rate mog_begin(oatgpu_ctx *c, int s, double learningRate)
     return r;
 }
 
+static u64 *thr_buf(oatgpu_ctx *c, int parity)
+{
+    return c->bb.thr + (size_t)parity * c->cfg.n_streams * (c->g.Palloc >> 6);
+}
+
+// The single-stage calls are synchronous and share scratch with the pipelined path:
+// wait until both HIP streams have drained.
+static int quiesce(oatgpu_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    c->back_pending[0] = c->back_pending[1] = false;
+    return OATGPU_OK;
+}
+
 static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rate &r)
 {
     MogLaunch a{};
-    a.frames = frames; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = c->bb.thr;
+    a.frames = frames; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = thr_buf(c, 0);
     a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0;
     a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
     a.mp = mogparams_of(c->cfg);
@@ -303,6 +344,8 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     if (rc) return rc;
     if (!bgr_in) return fail(c, OATGPU_E_INVALID, "null frame");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
     const size_t npx = (size_t)c->g.H * c->g.W;
     uint8_t *slot = c->frames + (size_t)s * npx * 3;
     HIPCHK(c, hipMemcpyAsync(slot, bgr_in, npx * 3, hipMemcpyHostToDevice, c->stream));
@@ -364,26 +407,22 @@ static void to_position(const ResultRec &r, oatgpu_position *o)
     o->a00 = r.a00; o->a10 = r.a10; o->a01 = r.a01;
 }
 
-// erode -> dilate -> blob for streams [s0, s0+n) starting from bb.thr; results to slot
-static int back_half(oatgpu_ctx *c, int s0, int n, int slot, hipEvent_t ev_mid)
+// erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
+// the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
+static int back_half(oatgpu_ctx *c, const u64 *thr, int s0, int n, int slot, hipStream_t st, hipEvent_t ev_mid)
 {
     const Geom &g = c->g;
-    const u64 *src = c->bb.thr;
+    const u64 *src = thr;
     if (c->cfg.erode > 1) {
-        launch_morph(g, src, c->bb.tmp, c->cfg.erode, true, s0, n, c->stream);
+        launch_morph(g, src, c->bb.tmp, c->cfg.erode, true, s0, n, st);
         src = c->bb.tmp;
     }
-    if (c->cfg.dilate > 1) {
-        launch_morph(g, src, c->bb.morph, c->cfg.dilate, false, s0, n, c->stream);
-        src = c->bb.morph;
-    }
-    c->last_morph = src;
-    if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, c->stream));
+    if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, st));
+    const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+    c->last_morph = dil ? c->bb.morph : src;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, c->bb, src, c->cfg.min_area, c->cfg.max_area, rd, s0, n, c->stream);
+    launch_blob(g, c->bb, src, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->res_host + (size_t)slot * c->cfg.n_streams + s0, rd + s0,
-                             (size_t)n * sizeof(ResultRec), hipMemcpyDeviceToHost, c->stream));
     return OATGPU_OK;
 }
 
@@ -393,14 +432,17 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
     if (rc) return rc;
     if (!in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W;
     HIPCHK(c, hipMemcpyAsync(c->aux_a, in, npx * channels, hipMemcpyHostToDevice, c->stream));
     RangeParams rp = range_of(c->cfg);
-    launch_inrange_bits(g, c->aux_a, channels, rp, c->bb.thr + (size_t)s * (g.Palloc >> 6), c->stream);
+    launch_inrange_bits(g, c->aux_a, channels, rp, thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
     const int slot = c->cfg.ring_depth;   // the extra slot
-    rc = back_half(c, s, 1, slot, nullptr);
+    rc = back_half(c, thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
     if (rc) return rc;
+    c->frame_no = 0;                       // next pipelined frame starts on parity 0 again
     HIPCHK(c, hipStreamSynchronize(c->stream));
     to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
     return OATGPU_OK;
@@ -421,13 +463,14 @@ static void prof_fold(oatgpu_ctx *c)
 {
     if (!c->prof_used) return;
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream_b);
     for (size_t i = 0; i < c->prof_used; ++i) {
         float a = 0, b = 0, d = 0, t = 0;
         ProfStep &p = c->prof_steps[i];
-        hipEventElapsedTime(&a, p.e[0], p.e[1]);
-        hipEventElapsedTime(&b, p.e[1], p.e[2]);
-        hipEventElapsedTime(&d, p.e[2], p.e[3]);
-        hipEventElapsedTime(&t, p.e[0], p.e[3]);
+        hipEventElapsedTime(&a, p.e[0], p.e[1]);   // fused per-pixel kernel (stream A)
+        hipEventElapsedTime(&b, p.e[2], p.e[3]);   // erode (stream B)
+        hipEventElapsedTime(&d, p.e[3], p.e[4]);   // dilate + labelling + sums + selection (stream B)
+        hipEventElapsedTime(&t, p.e[0], p.e[4]);   // latency of the frame through both streams
         c->prof_sum.steps += 1;
         c->prof_sum.mog_ms += a; c->prof_sum.morph_ms += b; c->prof_sum.blob_ms += d; c->prof_sum.total_ms += t;
     }
@@ -441,6 +484,8 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
     const int slot = (c->ring_head + c->ring_count) % c->cfg.ring_depth;
+    const int q = (int)(c->frame_no & 1);           // which threshold-bit buffer this frame uses
+    hipStream_t A = c->stream, B = c->stream_b;
 
     ProfStep *ps = nullptr;
     if (c->prof) {
@@ -453,12 +498,16 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
             }
         }
         ps = &c->prof_steps[c->prof_used++];
-        HIPCHK(c, hipEventRecord(ps->e[0], c->stream));
     }
 
-    // every camera stream advances one frame; launches are batched while the
-    // streams share a learning-rate schedule (they do unless the single-stage
-    // calls were used unevenly)
+    // Stream A: the fused per-pixel kernel of THIS frame may start while stream B is still
+    // analysing the previous frame's mask; it only has to wait for the back half that last
+    // read the threshold buffer it is about to overwrite (two frames ago).
+    if (c->back_pending[q]) HIPCHK(c, hipStreamWaitEvent(A, c->ev_back[q], 0));
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
+
+    // every camera stream advances one frame; launches are batched while the streams share a
+    // learning-rate schedule (they do unless the single-stage calls were used unevenly)
     std::vector<Rate> rates(n);
     for (int s = 0; s < n; ++s) rates[s] = mog_begin(c, s, lr);
     int s0 = 0;
@@ -466,15 +515,27 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         int s1 = s0 + 1;
         while (s1 < n && memcmp(&rates[s1], &rates[s0], sizeof(Rate)) == 0) ++s1;
         MogLaunch a = mog_launch_base(c, (const uint8_t *)frames_dev, rates[s0]);
-        launch_mog_fused(c->g, a, s0, s1 - s0, c->stream);
+        a.thr_bits = thr_buf(c, q);
+        launch_mog_fused(c->g, a, s0, s1 - s0, A);
         s0 = s1;
     }
     HIPCHK(c, hipGetLastError());
-    if (ps) HIPCHK(c, hipEventRecord(ps->e[1], c->stream));
-    int rc = back_half(c, 0, n, slot, ps ? ps->e[2] : nullptr);
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
+    HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
+
+    // Stream B: morphology + blob analysis of this frame.
+    HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
+    int rc = back_half(c, thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
     if (rc) return rc;
-    if (ps) HIPCHK(c, hipEventRecord(ps->e[3], c->stream));
-    HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
+    if (ps) {
+        if (c->cfg.erode <= 1) { /* e[3] was recorded right after e[2] */ }
+        HIPCHK(c, hipEventRecord(ps->e[4], B));
+    }
+    HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
+    HIPCHK(c, hipEventRecord(c->ev_back[q], B));
+    c->back_pending[q] = true;
+    c->frame_no++;
     c->ring_count++;
     return OATGPU_OK;
 }
@@ -525,7 +586,10 @@ extern "C" int oatgpu_read_mask(oatgpu_ctx *c, int32_t s, int32_t which, uint8_t
     if (rc) return rc;
     if (!out) return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const u64 *base = which == OATGPU_TAP_THRESHOLD ? c->bb.thr
+    rc = quiesce(c);
+    if (rc) return rc;
+    const u64 *last_thr = thr_buf(c, c->frame_no ? (int)((c->frame_no - 1) & 1) : 0);
+    const u64 *base = which == OATGPU_TAP_THRESHOLD ? last_thr
                     : which == OATGPU_TAP_MORPH ? c->last_morph
                     : which == OATGPU_TAP_FINAL ? c->bb.fin : nullptr;
     if (!base) return fail(c, OATGPU_E_INVALID, "unknown tap %d", which);
@@ -543,6 +607,8 @@ extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_use
     int rc = check_stream_ix(c, s);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures;
     uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;

@@ -86,7 +86,7 @@ void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix,
 
 // --- kernels_blob.hip ---
 struct BlobBuffers {
-    u64 *thr;        // [n][Palloc/64] inRange output
+    u64 *thr;        // [2][n][Palloc/64] inRange output, double-buffered across frames
     u64 *tmp;        // [n][Palloc/64] morphology ping
     u64 *morph;      // [n][Palloc/64] after erode/dilate
     u64 *fin;        // [n][Palloc/64] after 1-px frame zeroing
@@ -95,6 +95,7 @@ struct BlobBuffers {
     int *parent;     // [n][Palloc]    union-find over run heads (sparse)
     long long *acc;  // [n][Palloc][3] Green sums per root (sparse)
     u64 *best;       // [n]            packed selection key
+    unsigned *done;  // [n]            workgroup arrival counter of k_select
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -104,7 +105,9 @@ struct ResultRec {   // device-side result, one per stream per step
 
 void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode, int first_stream,
                   int n_streams, hipStream_t st);
-void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, double min_area,
+// src_bits: mask before dilation; dil_k > 1 fuses the dilation into the row scan.
+// results: device-visible (host-mapped) array indexed by stream.
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st);
 
 }  // namespace oatgpu
