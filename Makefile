@@ -30,3 +30,10 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle host clean
+
+# A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> oat_amd/lib/liboatgpu_px2.so
+variant:
+	@mkdir -p build/$(NAME) oat_amd/lib
+	for f in kernels_mog kernels_blob oatgpu_api; do $(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o oat_amd/lib/liboatgpu_$(NAME).so build/$(NAME)/*.o
+.PHONY: variant

@@ -196,6 +196,12 @@ __device__ __forceinline__ bool in_range3(int a, int b, int c, const RangeParams
            c >= rp.lo[2] && c <= rp.hi[2];
 }
 
+template <int N> struct VecOf;
+template <> struct VecOf<4> { typedef float4 F; typedef uchar4 B; };
+template <> struct VecOf<2> { typedef float2 F; typedef uchar2 B; };
+typedef VecOf<kPX>::F vecf;
+typedef VecOf<kPX>::B vecb;
+
 __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     __shared__ int sdiv[256];
@@ -205,44 +211,63 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
 
     const int s = first_stream + blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int base = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256;
+    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kWavePx;
     if (base >= g.P) return;                      // whole wave beyond the image (tail block)
 
     const size_t npx = (size_t)g.H * g.W;
     const uint8_t *frame = a.frames + (size_t)s * npx * 3;
-    float *st = a.state + (size_t)s * kMogPlanes * g.Palloc + base + 4 * lane;
-    uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + 4 * lane;
+    float *sbase = a.state + (size_t)s * mog_stream_floats(g.Palloc);
+    float *st = sbase + mog_plane_off(g.Palloc, 0, base) + kPX * lane;     // plane 0 of this wave's tile
+    const size_t PS = mog_plane_stride(g.Palloc);                           // plane k = st + k * PS
+#if OATGPU_TILED
+    uint8_t *nm = (uint8_t *)sbase + mog_count_off(g.Palloc, base) + kPX * lane;
+#else
+    uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + kPX * lane;
+#endif
 
-    // ---- load the mixture of this lane's four pixels: up to 25 x 16 B, only live modes ----
-    float W[kMaxMix][4], V[kMaxMix][4], M[kMaxMix][3][4];
-    int nmodes[4] = {0, 0, 0, 0};
-    if (!a.fresh) {
-        const uchar4 n4 = *(const uchar4 *)nm;
-        nmodes[0] = n4.x; nmodes[1] = n4.y; nmodes[2] = n4.z; nmodes[3] = n4.w;
-    }
-    const int nold0 = nmodes[0], nold1 = nmodes[1], nold2 = nmodes[2], nold3 = nmodes[3];
-    const int nmax_old = max(max(nold0, nold1), max(nold2, nold3));
+    // ---- load the mixture of this lane's pixels: mode 0 right away (almost every pixel has
+    // it), modes 1..4 only where some pixel of the lane has them (exec-masked vector loads) ----
+    float W[kMaxMix][kPX], V[kMaxMix][kPX], M[kMaxMix][3][kPX];
+    int nmodes[kPX], nold[kPX];
 #pragma unroll
-    for (int k = 0; k < kMaxMix; ++k) {
+    for (int j = 0; j < kPX; ++j) nmodes[j] = 0;
+    if (!a.fresh) {
+        const vecb n4 = *(const vecb *)nm;
+        const uint8_t *nb = (const uint8_t *)&n4;
+#pragma unroll
+        for (int j = 0; j < kPX; ++j) nmodes[j] = nb[j];
+        *(vecf *)W[0] = *(const vecf *)(st);
+        *(vecf *)V[0] = *(const vecf *)(st + (size_t)5 * PS);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(vecf *)M[0][c] = *(const vecf *)(st + (size_t)(10 + c) * PS);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPX; ++j) { W[0][j] = 0.f; V[0][j] = 0.f; M[0][0][j] = 0.f; M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
+    }
+    int nmax_old = 0;
+#pragma unroll
+    for (int j = 0; j < kPX; ++j) { nold[j] = nmodes[j]; nmax_old = max(nmax_old, nmodes[j]); }
+#pragma unroll
+    for (int k = 1; k < kMaxMix; ++k) {
         if (k < nmax_old) {
-            *(float4 *)W[k] = *(const float4 *)(st + (size_t)k * g.Palloc);
-            *(float4 *)V[k] = *(const float4 *)(st + (size_t)(5 + k) * g.Palloc);
+            *(vecf *)W[k] = *(const vecf *)(st + (size_t)k * PS);
+            *(vecf *)V[k] = *(const vecf *)(st + (size_t)(5 + k) * PS);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                *(float4 *)M[k][c] = *(const float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc);
+                *(vecf *)M[k][c] = *(const vecf *)(st + (size_t)(10 + 3 * k + c) * PS);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kPX; ++j) {
                 W[k][j] = 0.f; V[k][j] = 0.f; M[k][0][j] = 0.f; M[k][1][j] = 0.f; M[k][2][j] = 0.f;
             }
         }
     }
-    unsigned dvm = 0;           // modes whose variance/mean changed for any of the four pixels
-    bool wchg = false;          // weights changed for any of the four pixels
+    unsigned dvm = 0;           // modes whose variance/mean changed for any of the lane's pixels
+    bool wchg = false;          // weights changed for any of the lane's pixels
 
-    u64 words[4];
+    u64 words[kPX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kPX; ++j) {
         const int p = base + 64 * j + lane;
         const int y = p / g.Wp;
         const int x = p - y * g.Wp;
@@ -285,31 +310,41 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
     }
 
     // ---- store back only what changed (values not stored are bit-identical in HBM) ----
-    const int nmax_new = max(max(nmodes[0], nmodes[1]), max(nmodes[2], nmodes[3]));
+    int nmax_new = 0;
+    bool nchg = a.fresh != 0;
+#pragma unroll
+    for (int j = 0; j < kPX; ++j) { nmax_new = max(nmax_new, nmodes[j]); nchg |= (nmodes[j] != nold[j]); }
     const int nlive = max(nmax_old, nmax_new);
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
         if (wchg && k < nlive)
-            *(float4 *)(st + (size_t)k * g.Palloc) = *(const float4 *)W[k];
+            *(vecf *)(st + (size_t)k * PS) = *(const vecf *)W[k];
         if ((dvm >> k) & 1u) {
-            *(float4 *)(st + (size_t)(5 + k) * g.Palloc) = *(const float4 *)V[k];
+            *(vecf *)(st + (size_t)(5 + k) * PS) = *(const vecf *)V[k];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                *(float4 *)(st + (size_t)(10 + 3 * k + c) * g.Palloc) = *(const float4 *)M[k][c];
+                *(vecf *)(st + (size_t)(10 + 3 * k + c) * PS) = *(const vecf *)M[k][c];
         }
     }
-    if (a.fresh || nmodes[0] != nold0 || nmodes[1] != nold1 || nmodes[2] != nold2 || nmodes[3] != nold3)
-        *(uchar4 *)nm = make_uchar4((uint8_t)nmodes[0], (uint8_t)nmodes[1], (uint8_t)nmodes[2], (uint8_t)nmodes[3]);
+    if (nchg) {
+        vecb nv;
+        uint8_t *nb = (uint8_t *)&nv;
+#pragma unroll
+        for (int j = 0; j < kPX; ++j) nb[j] = (uint8_t)nmodes[j];
+        *(vecb *)nm = nv;
+    }
 
-    if (a.thr_bits && lane < 4) {
-        const u64 wsel = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+    if (a.thr_bits && lane < kPX) {
+        u64 wsel = words[0];
+#pragma unroll
+        for (int j = 1; j < kPX; ++j) wsel = (lane == j) ? words[j] : wsel;
         a.thr_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6) + lane] = wsel;
     }
 }
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
-    dim3 grid(g.Palloc / 1024, n_streams);
+    dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
     hipLaunchKernelGGL(k_mog_fused, grid, dim3(256), 0, st, g, a, first_stream);
 }
 
@@ -381,20 +416,37 @@ void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_
 }
 
 // ---- model checkpoint: device planes <-> OpenCV's logical AoS order ----
-__global__ __launch_bounds__(256) void k_state_export(Geom g, const float *state, const uint8_t *nmodes, int nmix,
+__device__ __forceinline__ float *state_elem(const Geom &g, float *sbase, int plane, int p)
+{
+    const int base = p - (p % kWavePx);
+    return sbase + mog_plane_off(g.Palloc, plane, base) + (mog_slot(p) - base);
+}
+__device__ __forceinline__ uint8_t *count_elem(const Geom &g, float *sbase, uint8_t *nmodes, int p)
+{
+    const int base = p - (p % kWavePx);
+#if OATGPU_TILED
+    (void)nmodes;
+    return (uint8_t *)sbase + mog_count_off(g.Palloc, base) + (mog_slot(p) - base);
+#else
+    (void)sbase;
+    return nmodes + mog_slot(p);
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint8_t *nmodes, int nmix,
                                                       uint8_t *modes_used, float *weight, float *variance,
                                                       float *mean)
 {
     const size_t npx = (size_t)g.H * g.W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
-        const int slot = mog_slot(y * g.Wp + x);
-        modes_used[i] = nmodes[slot];
+        const int p = y * g.Wp + x;
+        modes_used[i] = *count_elem(g, state, nmodes, p);
         for (int k = 0; k < nmix; ++k) {
-            weight[i * nmix + k] = state[(size_t)k * g.Palloc + slot];
-            variance[i * nmix + k] = state[(size_t)(5 + k) * g.Palloc + slot];
+            weight[i * nmix + k] = *state_elem(g, state, k, p);
+            variance[i * nmix + k] = *state_elem(g, state, 5 + k, p);
             for (int c = 0; c < 3; ++c)
-                mean[(i * nmix + k) * 3 + c] = state[(size_t)(10 + 3 * k + c) * g.Palloc + slot];
+                mean[(i * nmix + k) * 3 + c] = *state_elem(g, state, 10 + 3 * k + c, p);
         }
     }
 }
@@ -406,18 +458,18 @@ __global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint
     const size_t npx = (size_t)g.H * g.W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
-        const int slot = mog_slot(y * g.Wp + x);
-        nmodes[slot] = modes_used[i];
+        const int p = y * g.Wp + x;
+        *count_elem(g, state, nmodes, p) = modes_used[i];
         for (int k = 0; k < nmix; ++k) {
-            state[(size_t)k * g.Palloc + slot] = weight[i * nmix + k];
-            state[(size_t)(5 + k) * g.Palloc + slot] = variance[i * nmix + k];
+            *state_elem(g, state, k, p) = weight[i * nmix + k];
+            *state_elem(g, state, 5 + k, p) = variance[i * nmix + k];
             for (int c = 0; c < 3; ++c)
-                state[(size_t)(10 + 3 * k + c) * g.Palloc + slot] = mean[(i * nmix + k) * 3 + c];
+                *state_elem(g, state, 10 + 3 * k + c, p) = mean[(i * nmix + k) * 3 + c];
         }
     }
 }
 
-void launch_state_export(const Geom &g, const float *state, const uint8_t *nmodes, int nmix,
+void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix,
                          uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st)
 {
     hipLaunchKernelGGL(k_state_export, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, modes_used, weight,

@@ -201,7 +201,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_back[q], hipEventDisableTiming) == hipSuccess;
     }
-    A((void **)&c->state, n * kMogPlanes * PA * sizeof(float));
+    A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
     A((void **)&c->frames, n * npx * 3);
     A((void **)&c->aux_a, npx * 3);
@@ -227,6 +227,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     }
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb.thr, 0, 2 * n * NW * 8, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
@@ -616,7 +617,7 @@ extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_use
     HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
     HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
     HIPCHK(c, hipMalloc((void **)&d_m, npx * k * 12));
-    launch_state_export(g, c->state + (size_t)s * kMogPlanes * g.Palloc, c->nmodes + (size_t)s * g.Palloc, (int)k,
+    launch_state_export(g, c->state + (size_t)s * mog_stream_floats(g.Palloc), c->nmodes + (size_t)s * g.Palloc, (int)k,
                         d_mu, d_w, d_v, d_m, c->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && modes_used) e = hipMemcpyAsync(modes_used, d_mu, npx, hipMemcpyDeviceToHost, c->stream);
@@ -650,7 +651,7 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (e == hipSuccess) e = hipMemcpyAsync(d_v, variance, npx * k * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, mean, npx * k * 12, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        launch_state_import(g, c->state + (size_t)s * kMogPlanes * g.Palloc, c->nmodes + (size_t)s * g.Palloc, (int)k,
+        launch_state_import(g, c->state + (size_t)s * mog_stream_floats(g.Palloc), c->nmodes + (size_t)s * g.Palloc, (int)k,
                             d_mu, d_w, d_v, d_m, c->stream);
         e = hipGetLastError();
     }

@@ -30,19 +30,54 @@ struct Geom {
 //   plane 5..9   variance[k]
 //   plane 10+3k+c  mean[k][c]
 // Inside a plane the 256 pixels one wavefront owns are stored lane-interleaved:
-//   pixel p = base + 64*j + lane   (base multiple of 256, j in 0..3)
-//   slot    = base + 4*lane + j
-// so one float4 load per lane fetches that lane's four pixels (16 B/lane,
-// 1 KiB per wave instruction) and pixels {base+64j .. base+64j+63} -- one mask
-// word -- sit in component j of the 64 lanes.
+//   pixel p = base + 64*j + lane   (base multiple of 64*kPX, j in 0..kPX-1)
+//   slot    = base + kPX*lane + j
+// so one vector load per lane fetches that lane's kPX pixels (16 B/lane for
+// kPX = 4, 1 KiB per wave instruction) and pixels {base+64j .. base+64j+63} --
+// one mask word -- sit in component j of the 64 lanes.
 constexpr int kMogPlanes = 25;
 constexpr int kMaxMix = 5;
+#ifndef OATGPU_PX
+#define OATGPU_PX 4
+#endif
+constexpr int kPX = OATGPU_PX;            // pixels per lane of the MOG kernel (2 or 4)
+constexpr int kWavePx = 64 * kPX;         // pixels one wavefront owns
 
 __host__ __device__ inline int mog_slot(int p)
 {
-    int base = p & ~255, r = p & 255;
-    return base + 4 * (r & 63) + (r >> 6);
+    int base = p - (p % kWavePx), r = p % kWavePx;
+    return base + kPX * (r & 63) + (r >> 6);
 }
+
+// Where the planes live.  TILED (OATGPU_TILED=1, an A/B option; measured 3-4 % slower on MI355X): everything one wavefront needs is ONE contiguous
+// ~26 KB record -- 25 fp32 planes of kWavePx entries, then kWavePx mode counters (bytes) --
+// so a wave's 26 vector loads hit consecutive DRAM pages and one TLB entry instead of 26
+// streams that are 33 MB apart.  PLANAR (default): plane-major arrays of Palloc
+// entries, counters in a separate array.
+#ifndef OATGPU_TILED
+#define OATGPU_TILED 0
+#endif
+#if OATGPU_TILED
+constexpr int kTileFloats = kMogPlanes * kWavePx + kWavePx / 4;
+__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)(Palloc / kWavePx) * kTileFloats; }
+// float offset (within a stream) of `plane` for the wave tile that starts at pixel `base`
+__host__ __device__ inline size_t mog_plane_off(int Palloc, int plane, int base)
+{
+    (void)Palloc;
+    return (size_t)(base / kWavePx) * kTileFloats + (size_t)plane * kWavePx;
+}
+__host__ __device__ inline size_t mog_plane_stride(int Palloc) { (void)Palloc; return kWavePx; }
+// byte offset (within a stream's float array) of the mode counters of that tile
+__host__ __device__ inline size_t mog_count_off(int Palloc, int base)
+{
+    (void)Palloc;
+    return ((size_t)(base / kWavePx) * kTileFloats + (size_t)kMogPlanes * kWavePx) * 4;
+}
+#else
+__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)kMogPlanes * Palloc; }
+__host__ __device__ inline size_t mog_plane_off(int Palloc, int plane, int base) { return (size_t)plane * Palloc + base; }
+__host__ __device__ inline size_t mog_plane_stride(int Palloc) { return Palloc; }
+#endif
 
 struct MogParams {
     float Tb, TB, Tg, varInit, varMin, varMax, tau;
@@ -58,8 +93,8 @@ struct RangeParams {
 
 struct MogLaunch {
     const uint8_t *frames;   // [n][H*W*3] packed BGR
-    float *state;            // [n][25][Palloc]
-    uint8_t *nmodes;         // [n][Palloc]  (same lane-interleaved slots)
+    float *state;            // [n][mog_stream_floats(Palloc)]
+    uint8_t *nmodes;         // planar layout only: [n][Palloc] counters (same lane-interleaved slots)
     u64 *thr_bits;           // [n][Palloc/64] or nullptr
     uint8_t *out_bgr;        // [n][H*W*3] masked frame or nullptr
     uint8_t *out_mask;       // [n][H*W] {0,127,255} or nullptr
@@ -78,7 +113,8 @@ void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, cons
                          u64 *bits, hipStream_t st);
 void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st);
 // model checkpoint: logical (OpenCV AoS) <-> device planes
-void launch_state_export(const Geom &g, const float *state, const uint8_t *nmodes, int nmix,
+// state / nmodes point at ONE stream's model
+void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix,
                          uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st);
 void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix,
                          const uint8_t *modes_used, const float *weight, const float *variance,

@@ -6,7 +6,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "liboatgpu.so")
+    """The product library; OATGPU_LIB overrides the path (A/B builds of kernel variants)."""
+    return os.environ.get("OATGPU_LIB") or os.path.join(_HERE, "lib", "liboatgpu.so")
 
 
 class OatGpuError(RuntimeError):
