@@ -1,0 +1,210 @@
+// component.hpp -- the callers either side of the hot path, mirrored from jonnew/Oat:
+//
+//   oat::Component::run / runComponent   lib/base/Component.cpp:36-76   (SIGINT -> quit, END -> exit)
+//   oat::FrameFilter::connectToNode/process    src/framefilter/FrameFilter.cpp:37-98
+//   oat::PositionDetector::connectToNode/process  src/positiondetector/PositionDetector.cpp:40-99
+//
+// The virtual filter() / detectPosition() are implemented over the C ABI of liboatgpu.so.
+#pragma once
+
+#include "shmemdf.hpp"
+#include "../../include/oatgpu.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <memory>
+
+namespace oat {
+
+volatile sig_atomic_t quit = 0;
+
+inline void sigHandler(int) { quit = 1; }
+
+class Component {
+public:
+    virtual ~Component() {}
+    virtual std::string name() const = 0;
+    // lib/base/Component.cpp:50-76
+    int run()
+    {
+        std::signal(SIGINT, sigHandler);
+        std::signal(SIGTERM, sigHandler);
+        try {
+            if (!connectToNode()) return 0;
+            int eos = 0;
+            while (!eos && !quit) eos = process();
+        } catch (const std::exception &e) {
+            std::cerr << name() << ": " << e.what() << std::endl;   // whoError(name, what)
+            return -1;
+        }
+        std::cout << name() << ": Exiting." << std::endl;
+        return 0;
+    }
+
+protected:
+    virtual bool connectToNode() = 0;
+    virtual int process() = 0;
+};
+
+struct GpuCtx {
+    oatgpu_ctx *ctx{nullptr};
+    ~GpuCtx() { if (ctx) oatgpu_destroy(ctx); }
+    void create(const oatgpu_config &cfg)
+    {
+        ctx = oatgpu_create(&cfg);
+        if (!ctx) throw std::runtime_error(std::string("oatgpu_create: ") + oatgpu_last_error(nullptr));
+    }
+    void check(int rc) const
+    {
+        if (rc != OATGPU_OK) throw std::runtime_error(std::string("oatgpu: ") + oatgpu_last_error(ctx));
+    }
+};
+
+// src/framefilter/FrameFilter.h:36-86
+class FrameFilter : public Component {
+public:
+    FrameFilter(const std::string &source, const std::string &sink)
+        : name_("framefilt[" + source + "->" + sink + "]"), frame_source_address_(source), frame_sink_address_(sink) {}
+    std::string name() const override { return name_; }
+
+protected:
+    virtual void filter(Frame &frame) = 0;                  // FrameFilter.h:64
+    virtual PixelColor sink_color(PixelColor in) const { return in; }
+    virtual void configure_for(const FrameParams &) {}
+
+    // FrameFilter.cpp:37-57
+    bool connectToNode() override
+    {
+        frame_source_.touch(frame_source_address_);
+        if (frame_source_.connect() != SourceState::CONNECTED) return false;
+        auto p = frame_source_.parameters();
+        configure_for(p);
+        const PixelColor out = sink_color(p.color);
+        const size_t bytes = p.rows * p.cols * color_bytes(out);
+        frame_sink_.bind(frame_sink_address_, bytes);
+        shared_frame_ = frame_sink_.retrieve(p.rows, p.cols, color_cvtype(out), out);
+        return true;
+    }
+    // FrameFilter.cpp:59-98
+    int process() override
+    {
+        Frame internal_frame;
+        if (frame_source_.wait() == NodeState::END) return 1;
+        frame_source_.copyTo(internal_frame);
+        frame_source_.post();
+
+        filter(internal_frame);
+
+        frame_sink_.wait();
+        internal_frame.copyTo(shared_frame_);
+        frame_sink_.post();
+        return 0;
+    }
+
+    std::string name_, frame_source_address_, frame_sink_address_;
+    Source<Frame> frame_source_;
+    Sink<Frame> frame_sink_;
+    Frame shared_frame_;
+};
+
+// src/positiondetector/PositionDetector.h:43-90
+class PositionDetector : public Component {
+public:
+    PositionDetector(const std::string &source, const std::string &sink)
+        : name_("posidet[" + source + "->" + sink + "]"), frame_source_address_(source), position_sink_address_(sink) {}
+    std::string name() const override { return name_; }
+
+protected:
+    virtual void detectPosition(Frame &frame, Position2D &position) = 0;   // PositionDetector.h:65
+    virtual void configure_for(const FrameParams &) {}
+    PixelColor required_color_{PIX_BGR};
+
+    // PositionDetector.cpp:40-56
+    bool connectToNode() override
+    {
+        frame_source_.touch(frame_source_address_);
+        if (frame_source_.connect(required_color_) != SourceState::CONNECTED) return false;
+        configure_for(frame_source_.parameters());
+        position_sink_.bind(position_sink_address_, position_sink_address_);
+        shared_position_ = position_sink_.retrieve();
+        return true;
+    }
+    // PositionDetector.cpp:58-99
+    int process() override
+    {
+        Frame internal_frame;
+        Position2D internal_pos("");
+        if (frame_source_.wait() == NodeState::END) return 1;
+        frame_source_.copyTo(internal_frame);
+        frame_source_.post();
+
+        internal_pos.set_sample(internal_frame.sample());
+        detectPosition(internal_frame, internal_pos);
+
+        position_sink_.wait();
+        *shared_position_ = internal_pos;
+        position_sink_.post();
+        return 0;
+    }
+
+    std::string name_, frame_source_address_, position_sink_address_;
+    Source<Frame> frame_source_;
+    Sink<Position2D> position_sink_;
+    Position2D *shared_position_{nullptr};
+};
+
+// ---- option parsing: "TYPE SOURCE SINK [--key value | -k value | --flag]" with the reference's
+// names (SURVEY.md 8a "Option surface"); array values are TOML literals like "[0,256]". ----
+struct Options {
+    std::vector<std::string> positional;
+    std::map<std::string, std::string> kv;
+
+    static Options parse(int argc, char **argv, const std::map<std::string, std::string> &short2long,
+                         const std::vector<std::string> &flags = {})
+    {
+        Options o;
+        for (int i = 1; i < argc; ++i) {
+            std::string a = argv[i];
+            bool is_num = a.size() > 1 && a[0] == '-' && (isdigit((unsigned char)a[1]) || a[1] == '.');
+            if (a.size() > 1 && a[0] == '-' && !is_num) {
+                std::string key;
+                if (a[1] == '-') key = a.substr(2);
+                else {
+                    auto it = short2long.find(a.substr(1));
+                    if (it == short2long.end()) throw std::runtime_error("unrecognised option '" + a + "'");
+                    key = it->second;
+                }
+                bool is_flag = false;
+                for (auto &f : flags) if (f == key) is_flag = true;
+                if (is_flag) { o.kv[key] = "true"; continue; }
+                if (i + 1 >= argc) throw std::runtime_error("option '" + a + "' needs a value");
+                o.kv[key] = argv[++i];
+            } else {
+                o.positional.push_back(a);
+            }
+        }
+        return o;
+    }
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    double num(const std::string &k, double def, double lo, double hi) const
+    {
+        if (!has(k)) return def;
+        char *end = nullptr;
+        double v = strtod(kv.at(k).c_str(), &end);
+        if (end == kv.at(k).c_str()) throw std::runtime_error("'" + k + "' must be numeric");
+        if (v < lo || v > hi) throw std::runtime_error("'" + k + "' out of range");   // TOMLSanitize.h:218-277
+        return v;
+    }
+    // "[a,b]" -> 2 numbers (TOMLSanitize.h:279-344 getArray<T,2>)
+    bool arr2(const std::string &k, double &a, double &b) const
+    {
+        if (!has(k)) return false;
+        const std::string &s = kv.at(k);
+        if (sscanf(s.c_str(), " [ %lf , %lf ]", &a, &b) != 2) throw std::runtime_error("'" + k + "' must be a 2-element array, e.g. [0,256]");
+        return true;
+    }
+};
+
+}  // namespace oat

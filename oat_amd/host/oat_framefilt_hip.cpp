@@ -1,0 +1,92 @@
+// oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]
+//   TYPE  mog   MI355X replacement of `oat framefilt mog`  (src/framefilter/BackgroundSubtractorMOG.cpp)
+//         col   MI355X replacement of `oat framefilt col`  (src/framefilter/ColorConvert.cpp), BGR->HSV only
+// Drop-in: same positional arguments, same option names (src/framefilter/main.cpp:91-296).
+#include "component.hpp"
+
+using namespace oat;
+
+class BackgroundSubtractorMOG : public FrameFilter {
+public:
+    using FrameFilter::FrameFilter;
+    double learning_coeff_{0.0};    // BackgroundSubtractorMOG.h:76
+    int gpu_index_{0};
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        if (p.color != PIX_BGR) throw std::runtime_error("framefilt mog (hip) needs BGR frames");
+        oatgpu_config cfg;
+        oatgpu_default_config(&cfg);
+        cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.n_streams = 1;
+        gpu_.create(cfg);
+    }
+    // BackgroundSubtractorMOG.cpp:114-127 (CPU-branch semantics: MOG2, shadows kept)
+    void filter(Frame &frame) override
+    {
+        gpu_.check(oatgpu_mog_filter(gpu_.ctx, 0, frame.data(), frame.data(), learning_coeff_));
+    }
+    GpuCtx gpu_;
+};
+
+class ColorConvert : public FrameFilter {
+public:
+    using FrameFilter::FrameFilter;
+    PixelColor color_{PIX_HSV};
+
+protected:
+    PixelColor sink_color(PixelColor in) const override
+    {
+        if (in != PIX_BGR || color_ != PIX_HSV)   // color_conv_table, Color.h:46-51: only BGR->HSV is on the hot path
+            throw std::runtime_error("framefilt col (hip) converts BGR to HSV only");
+        return PIX_HSV;
+    }
+    void configure_for(const FrameParams &p) override
+    {
+        oatgpu_config cfg;
+        oatgpu_default_config(&cfg);
+        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols;
+        gpu_.create(cfg);
+    }
+    // ColorConvert.cpp:101-107
+    void filter(Frame &frame) override
+    {
+        gpu_.check(oatgpu_bgr2hsv(gpu_.ctx, frame.data(), frame.data()));
+        frame.set_color(PIX_HSV);
+    }
+    GpuCtx gpu_;
+};
+
+static void usage()
+{
+    std::cout << "Usage: oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]\n"
+                 "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: BGR -> HSV colour conversion on an MI355X\n"
+                 "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n      --gpu-index          HIP device ordinal\n"
+                 "col:  -C, --color             HSV\n";
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"h", "help"}}, {"help"});
+        if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
+        const std::string type = o.positional[0];
+        std::unique_ptr<Component> comp;
+        if (type == "mog") {
+            auto f = std::make_unique<BackgroundSubtractorMOG>(o.positional[1], o.positional[2]);
+            f->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);     // BackgroundSubtractorMOG.cpp:86-88
+            f->gpu_index_ = (int)o.num("gpu-index", 0, 0, 64);
+            comp = std::move(f);
+        } else if (type == "col") {
+            auto f = std::make_unique<ColorConvert>(o.positional[1], o.positional[2]);
+            if (o.has("color") && o.kv["color"] != "HSV") throw std::runtime_error("only -C HSV is supported");
+            comp = std::move(f);
+        } else {
+            throw std::runtime_error("Selected TYPE is invalid.");
+        }
+        return comp->run();
+    } catch (const std::exception &e) {
+        std::cerr << "oat-framefilt-hip: " << e.what() << std::endl;
+        return -1;
+    }
+}

@@ -1,0 +1,77 @@
+// oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]
+//   TYPE  hsv     replacement of `oat posidet hsv`    (src/positiondetector/HSVDetector.cpp)
+//         thresh  replacement of `oat posidet thresh` (src/positiondetector/SimpleThreshold.cpp)
+// Same positional arguments and option names as src/positiondetector/main.cpp:85-271.
+#include "component.hpp"
+
+#include <cfloat>
+
+using namespace oat;
+
+class GpuDetector : public PositionDetector {
+public:
+    GpuDetector(const std::string &src, const std::string &snk, bool hsv) : PositionDetector(src, snk), hsv_(hsv)
+    {
+        oatgpu_default_config(&cfg_);
+        if (hsv) { required_color_ = PIX_HSV; cfg_.erode = 0; cfg_.dilate = 10; }       // HSVDetector.cpp:42-46
+        else { required_color_ = PIX_GREY; cfg_.erode = 0; cfg_.dilate = 0; }           // SimpleThreshold.cpp:42-46
+    }
+    oatgpu_config cfg_;
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        cfg_.rows = (int)p.rows; cfg_.cols = (int)p.cols; cfg_.n_streams = 1;
+        gpu_.create(cfg_);
+    }
+    // HSVDetector.cpp:142-173 / SimpleThreshold.cpp:114-134
+    void detectPosition(Frame &frame, Position2D &position) override
+    {
+        oatgpu_position r;
+        gpu_.check(hsv_ ? oatgpu_detect_hsv(gpu_.ctx, 0, frame.data(), &r) : oatgpu_detect_thresh(gpu_.ctx, 0, frame.data(), &r));
+        position.position_valid = r.valid != 0;                   // DetectorFunc.cpp:46,58-60
+        if (r.valid) { position.position.x = r.x; position.position.y = r.y; }
+    }
+    bool hsv_;
+    GpuCtx gpu_;
+};
+
+static void usage()
+{
+    std::cout << "Usage: oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]\nTYPE\n  hsv | thresh\n"
+                 "hsv:    -H/-S/-V [min,max] in [0,256]  -e erode  -d dilate (default 10)  -a [min,max] area\n"
+                 "thresh: -T [min,max]  -e erode  -d dilate  -a [min,max] area\n";
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        Options o = Options::parse(argc, argv,
+            {{"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"T", "thresh"}, {"e", "erode"}, {"d", "dilate"},
+             {"a", "area"}, {"t", "tune"}, {"h", "help"}}, {"help", "tune"});
+        if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
+        const std::string type = o.positional[0];
+        if (type != "hsv" && type != "thresh") throw std::runtime_error("Selected TYPE is invalid.");
+        if (o.has("tune")) throw std::runtime_error("--tune needs a GUI and is not available in the hip detector");
+        auto d = std::make_unique<GpuDetector>(o.positional[1], o.positional[2], type == "hsv");
+        double a, b;
+        auto range = [](double x, double y, const char *what) {
+            if (x < 0 || x > 256 || y < 0 || y > 256) throw std::runtime_error(std::string("Values of ") + what + " should be between 0 and 256.");
+        };
+        if (type == "hsv") {
+            if (o.arr2("h-thresh", a, b)) { range(a, b, "h-thresh"); d->cfg_.h_lo = (int)a; d->cfg_.h_hi = (int)b; }
+            if (o.arr2("s-thresh", a, b)) { range(a, b, "s-thresh"); d->cfg_.s_lo = (int)a; d->cfg_.s_hi = (int)b; }
+            if (o.arr2("v-thresh", a, b)) { range(a, b, "v-thresh"); d->cfg_.v_lo = (int)a; d->cfg_.v_hi = (int)b; }
+        } else if (o.arr2("thresh", a, b)) { range(a, b, "thresh"); d->cfg_.h_lo = (int)a; d->cfg_.h_hi = (int)b; }
+        if (o.has("erode")) d->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
+        if (o.has("dilate")) d->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
+        if (o.arr2("area", a, b)) {
+            if (a >= b) throw std::runtime_error("Max area should be larger than min area.");   // HSVDetector.cpp:135
+            d->cfg_.min_area = a; d->cfg_.max_area = b;
+        }
+        return d->run();
+    } catch (const std::exception &e) {
+        std::cerr << "oat-posidet-hip: " << e.what() << std::endl;
+        return -1;
+    }
+}

@@ -1,0 +1,62 @@
+// oat-track-hip SOURCE SINK [CONFIGURATION]
+// The whole chain  framefilt mog -> framefilt col -C HSV -> posidet hsv  in ONE process and ONE
+// fused device pass per frame: BGR oat::Frame in, oat::Position2D out (one token out per token
+// in, carrying the frame's Sample -- PositionDetector.cpp:80).  Options are the union of the
+// three stock components' (-a is mog's adaptation coefficient; the detector's area is --area).
+#include "component.hpp"
+
+using namespace oat;
+
+class FusedTracker : public PositionDetector {
+public:
+    FusedTracker(const std::string &src, const std::string &snk) : PositionDetector(src, snk)
+    {
+        oatgpu_default_config(&cfg_);
+        required_color_ = PIX_BGR;
+        name_ = "track[" + src + "->" + snk + "]";
+    }
+    oatgpu_config cfg_;
+    double learning_coeff_{0.0};
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        cfg_.rows = (int)p.rows; cfg_.cols = (int)p.cols; cfg_.n_streams = 1;
+        gpu_.create(cfg_);
+    }
+    void detectPosition(Frame &frame, Position2D &position) override
+    {
+        const uint8_t *f = frame.data();
+        oatgpu_position r;
+        gpu_.check(oatgpu_track_batch(gpu_.ctx, &f, 1, learning_coeff_, &r));
+        position.position_valid = r.valid != 0;
+        if (r.valid) { position.position.x = r.x; position.position.y = r.y; }
+    }
+    GpuCtx gpu_;
+};
+
+int main(int argc, char **argv)
+{
+    try {
+        Options o = Options::parse(argc, argv,
+            {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
+             {"d", "dilate"}, {"h", "help"}}, {"help"});
+        if (o.has("help") || o.positional.size() != 2) {
+            std::cout << "Usage: oat-track-hip SOURCE SINK [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n";
+            return o.has("help") ? 0 : -1;
+        }
+        auto t = std::make_unique<FusedTracker>(o.positional[0], o.positional[1]);
+        t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
+        double a, b;
+        if (o.arr2("h-thresh", a, b)) { t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b; }
+        if (o.arr2("s-thresh", a, b)) { t->cfg_.s_lo = (int)a; t->cfg_.s_hi = (int)b; }
+        if (o.arr2("v-thresh", a, b)) { t->cfg_.v_lo = (int)a; t->cfg_.v_hi = (int)b; }
+        if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
+        if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
+        if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }
+        return t->run();
+    } catch (const std::exception &e) {
+        std::cerr << "oat-track-hip: " << e.what() << std::endl;
+        return -1;
+    }
+}

@@ -1,0 +1,115 @@
+"""The C++ drop-in side: shm transport protocol (CPU) and the component pipeline (GPU).
+
+BASELINE config 1 plumbing:  frameserve -> framefilt mog -> framefilt col -C HSV -> posidet hsv,
+one OS process per component over named POSIX shm nodes, plus the fused single-process
+oat-track-hip; positions must equal the CPU oracle chain frame by frame, and every token must
+carry its frame's sample count (PositionDetector.cpp:80)."""
+import json
+import os
+import subprocess
+import time
+import uuid
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "bin")
+
+
+@pytest.fixture(scope="module")
+def host_bins():
+    subprocess.check_call(["make", "-s", "-j4", "-C", ROOT, "host"])
+    return BIN
+
+
+def test_shm_protocol_scenarios(host_bins):
+    """Reference test/shmemdf/*_test.cpp scenarios restated in oat_amd/host/test_shmemdf.cpp."""
+    out = subprocess.run([os.path.join(host_bins, "test_shmemdf"), "oat_t_" + uuid.uuid4().hex[:8]],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failures" in out.stdout
+
+
+def test_binaries_exist_and_print_usage(host_bins):
+    for b in ("oat-framefilt-hip", "oat-posidet-hip", "oat-track-hip", "oat-frameserve-raw", "oat-posi-cout"):
+        r = subprocess.run([os.path.join(host_bins, b), "--help"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "Usage" in r.stdout, (b, r.stdout, r.stderr)
+    # wrong TYPE -> the reference's message and exit code -1 (framefilter/main.cpp:200, :278-295)
+    r = subprocess.run([os.path.join(host_bins, "oat-posidet-hip"), "nope", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Selected TYPE is invalid." in r.stderr
+
+
+def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
+    """Token discipline of the transport alone: N frames in -> N tokens seen, in order."""
+    # a Position2D-typed reader must refuse a Frame node (Source<T> type check)
+    rows, cols, n = 4, 6, 5
+    raw = tmp_path / "f.raw"
+    np.arange(rows * cols * 3, dtype=np.uint8).tofile(raw)
+    addr = "oat_t_" + uuid.uuid4().hex[:8]
+    reader = subprocess.Popen([os.path.join(host_bins, "oat-posi-cout"), addr], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    feeder = subprocess.Popen([os.path.join(host_bins, "oat-frameserve-raw"), addr, "-f", str(raw), "--rows",
+                               str(rows), "--cols", str(cols), "-n", str(n)], stderr=subprocess.PIPE, text=True)
+    out, err = reader.communicate(timeout=30)
+    feeder.wait(timeout=30)
+    assert reader.returncode == 255 and "Type mismatch" in err
+    subprocess.run([os.path.join(host_bins, "oat-clean-hip"), addr], capture_output=True)
+
+
+def _run_pipeline(host_bins, tmp_path, frames, fused):
+    rows, cols = frames[0].shape[:2]
+    raw = tmp_path / "frames.raw"
+    np.stack(frames).tofile(raw)
+    tag = "oat_t_" + uuid.uuid4().hex[:8]
+    a_raw, a_filt, a_hsv, a_pos = (tag + s for s in ("raw", "filt", "hsv", "pos"))
+    det = ["-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7"]
+    procs = []
+    B = lambda n: os.path.join(host_bins, n)
+    reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
+    if fused:
+        procs.append(subprocess.Popen([B("oat-track-hip"), a_raw, a_pos, "-a", "0.01", "--area", "[20,100000]"] + det))
+    else:
+        procs.append(subprocess.Popen([B("oat-posidet-hip"), "hsv", a_hsv, a_pos, "-a", "[20,100000]"] + det))
+        procs.append(subprocess.Popen([B("oat-framefilt-hip"), "col", a_filt, a_hsv, "-C", "HSV"]))
+        procs.append(subprocess.Popen([B("oat-framefilt-hip"), "mog", a_raw, a_filt, "-a", "0.01"]))
+    time.sleep(3.0)          # every consumer has touch()ed its node before the first token exists
+    feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols",
+                               str(cols), "-n", str(len(frames)), "-r", "200"])
+    try:
+        out, _ = reader.communicate(timeout=180)
+        feeder.wait(timeout=60)
+        for p in procs:
+            p.wait(timeout=60)
+    finally:
+        for p in procs + [feeder, reader]:
+            if p.poll() is None:
+                p.kill()
+        subprocess.run([B("oat-clean-hip"), a_raw, a_filt, a_hsv, a_pos], capture_output=True)
+    assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
+    return [json.loads(l) for l in out.splitlines() if l.strip()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_component_pipeline_matches_oracle(host_bins, tmp_path, fused):
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 480, 640, 24
+    st = SyntheticStream(rows, cols, 3, n_discs=2)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(n)]
+    got = _run_pipeline(host_bins, tmp_path, frames, fused)
+    assert len(got) == n                                   # exactly one token out per token in
+    orc = O.Mog2(rows, cols, 3)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    hits = 0
+    for t, (f, g) in enumerate(zip(frames, got)):
+        want, _ = O.chain_step(orc, f, 0.01, p)
+        assert g["tick"] == t + 1 and g["usec"] == (t + 1) * 5000      # Sample propagated (200 Hz)
+        assert g["pos_ok"] == want["valid"], t
+        if want["valid"]:
+            hits += 1
+            assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, t
+    assert hits >= n - 2
