@@ -102,7 +102,7 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
             break
     return dict(value=n / el, unit="frames/s", cores=ncores, kind="port",
                 sample=f"{n} frames of one {wl['cols']}x{wl['rows']} stream, {el:.1f} s, oracle chain "
-                       f"(MOG2 rows over {ncores} threads; hsv/inRange/morphology/contours 1 thread)")
+                       f"(MOG2, HSV, inRange, morphology rows over {ncores} threads; contour following 1 thread)")
 
 
 def make_pool_device(rows, cols, ns, nframes, rank, dev):
@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=48, help="distinct frame sets resident in HBM")
+    ap.add_argument("--input", default="device", choices=["device", "host"],
+                    help="device: frames resident in HBM (the headline); host: pageable host frames through "
+                         "oatgpu_track_batch, i.e. PCIe-inclusive (reported in DESIGN.md, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -197,7 +200,17 @@ def main():
 
     positions = []
 
+    host_pool = None
+    if args.input == "host":
+        host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool[:8]]
+
     def run(nsteps, keep=False):
+        if host_pool is not None:                      # synchronous host-buffer entry point
+            for i in range(nsteps):
+                r = hp.track(host_pool[(i + 1) % len(host_pool)])
+                if keep:
+                    positions.append(r)
+            return
         for i in range(nsteps):
             if hp.outstanding() == ring:
                 r = hp.collect()
@@ -237,6 +250,15 @@ def main():
             dist.destroy_process_group()
         return
 
+    # real HBM bytes per K1 launch from the committed PMC passes (profiles/collect_pmc.sh writes
+    # the file; the counters cannot be read from inside this process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(args.workload, {}).get("k_mog_fused_bytes_per_launch")
+    except Exception:
+        traffic = None
+
     total_streams = ns * world
     fps = total_streams * K / elapsed
     px_per_launch = rows * cols * ns
@@ -262,7 +284,9 @@ def main():
         "fps_per_gpu": fps / world,
         "hbm_roofline_frac_whole_step": BYTES_PER_PIXEL * px_per_launch / (elapsed / K) / 1e9 / HBM_PEAK_GBPS,
         "roofline": {"bound": "hbm", "kernel": "k_mog_fused", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "note": "achieved = ALGORITHMIC 205 B/px / K1 time; K1 skips planes of dead modes and "
+                             "unchanged planes, so real traffic (PMC) is below algorithmic and frac may exceed 1",
                      "bytes_per_launch": BYTES_PER_PIXEL * px_per_launch, "avg_launch_ms": mog_ms},
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),
@@ -270,6 +294,7 @@ def main():
         "positions_found": n_found,
         "positions_expected": total_streams * K,
         "parity": parity,
+        "input": args.input,
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, [p[0] for p in pool_host])

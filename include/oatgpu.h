@@ -55,6 +55,8 @@ typedef struct oatgpu_config {
     int32_t n_streams;         /* camera streams batched in this context      */
     int32_t rows, cols;        /* frame geometry, identical for all streams   */
     int32_t ring_depth;        /* outstanding track_enqueue results (>=1)     */
+    int32_t channels;          /* 3: BGR frames (mog -> col HSV -> posidet hsv)
+                                  1: GREY frames (mog -> posidet thresh; -T = h_lo/h_hi) */
 
     /* --- MOG2 (BackgroundSubtractorMOG.cpp:82-83) --- */
     int32_t history;           /* 500 */
@@ -151,12 +153,13 @@ int oatgpu_detect_thresh(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *grey
 /* One frame for EVERY stream of the context (the whole chain
  * FrameFilter::process -> ColorConvert -> PositionDetector::process,
  * FrameFilter.cpp:59-98, PositionDetector.cpp:58-99, minus the shm hand-offs).
- * frames_host[i] -> rows*cols*3 BGR bytes of stream i.  out[n_streams]. */
+ * frames_host[i] -> rows*cols*channels bytes of stream i.  out[n_streams].
+ * With channels == 1 the chain is framefilt mog (GREY) -> posidet thresh. */
 int oatgpu_track_batch(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n,
                        double learning_rate, oatgpu_position *out);
 
 /* Same with the frames already resident in device memory:
- * frames_dev = n_streams*rows*cols*3 bytes, stream-major. */
+ * frames_dev = n_streams*rows*cols*channels bytes, stream-major. */
 int oatgpu_track_batch_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate,
                            oatgpu_position *out);
 
@@ -179,7 +182,7 @@ enum {
 int oatgpu_read_mask(oatgpu_ctx *ctx, int32_t stream_ix, int32_t which, uint8_t *out);
 
 /* MOG2 model of one stream in the oracle's (OpenCV's) logical layout:
- * modes_used[rows*cols], weight/variance[rows*cols*nmix], mean[rows*cols*nmix*3].
+ * modes_used[rows*cols], weight/variance[rows*cols*nmix], mean[rows*cols*nmix*channels].
  * Entries of unused modes (>= modes_used) are unspecified on get. */
 int oatgpu_mog_get_state(oatgpu_ctx *ctx, int32_t stream_ix, uint8_t *modes_used, float *weight,
                          float *variance, float *mean, int32_t *nframes);

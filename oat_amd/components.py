@@ -59,6 +59,8 @@ class _Context:
             setattr(cfg, k, v)
         self.cfg = cfg
         self.rows, self.cols, self.n_streams = rows, cols, n_streams
+        self.channels = cfg.channels
+        self.frame_shape = (rows, cols, 3) if cfg.channels == 3 else (rows, cols)
         self.ctx = self.lib.oatgpu_create(C.byref(cfg))
         if not self.ctx:
             raise ffi.OatGpuError(-1, (self.lib.oatgpu_last_error(None) or b"").decode())
@@ -88,7 +90,7 @@ class _Context:
         nm = np.empty(n, np.uint8)
         w = np.empty((n, k), np.float32)
         v = np.empty((n, k), np.float32)
-        m = np.empty((n, k, 3), np.float32)
+        m = np.empty((n, k, self.channels), np.float32)
         nf = C.c_int32(0)
         self._chk(self.lib.oatgpu_mog_get_state(self.ctx, stream, ffi.u8(nm), ffi.f32(w), ffi.f32(v), ffi.f32(m),
                                                 C.byref(nf)))
@@ -112,14 +114,14 @@ class BackgroundSubtractorMOG(_Context):
 
     def filter(self, frame, stream=0):
         """In place, like FrameFilter::filter(cv::Mat&); also returns the frame."""
-        f = _frame(frame, (self.rows, self.cols, 3))
+        f = _frame(frame, self.frame_shape)
         out = frame if (isinstance(frame, np.ndarray) and frame.flags.c_contiguous and frame.dtype == np.uint8) else f
         self._chk(self.lib.oatgpu_mog_filter(self.ctx, stream, ffi.u8(f), ffi.u8(out), self.learning_coeff_))
         return out
 
     def apply(self, frame, learning_rate=None, stream=0):
         """cv::BackgroundSubtractorMOG2::apply: returns the {0,127,255} mask."""
-        f = _frame(frame, (self.rows, self.cols, 3))
+        f = _frame(frame, self.frame_shape)
         mask = np.empty((self.rows, self.cols), np.uint8)
         lr = self.learning_coeff_ if learning_rate is None else float(learning_rate)
         self._chk(self.lib.oatgpu_mog_apply(self.ctx, stream, ffi.u8(f), ffi.u8(mask), lr))
@@ -203,8 +205,8 @@ class HotPath(_Context):
         return [Position2D.from_c(p) for p in self._pos]
 
     def track(self, frames):
-        """frames: sequence of n_streams host arrays (rows, cols, 3)."""
-        fs = [_frame(f, (self.rows, self.cols, 3)) for f in frames]
+        """frames: sequence of n_streams host arrays (rows, cols, 3), or (rows, cols) when channels == 1."""
+        fs = [_frame(f, self.frame_shape) for f in frames]
         ptrs = (ffi._u8p * len(fs))(*[ffi.u8(f) for f in fs])
         self._chk(self.lib.oatgpu_track_batch(self.ctx, ptrs, len(fs), self.learning_coeff_, self._pos))
         return self._out()

@@ -363,8 +363,17 @@ __global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_
     const u64 DL = (D << 1) | (dnP >> 63), DR = (D >> 1) | (dnN << 63);
 
     u64 cand = cur & ~(L & R & U & D);
-    const u64 Tc = trans[rc + w];
-    const int cc = carry[rc + w];
+    const u64 Tc = trans[rc + w], Tu = trans[ru + w], Td = trans[rd + w];
+    const int cc = carry[rc + w], cu = carry[ru + w], cd = carry[rd + w];
+
+    // Consecutive border pixels of one edge look at the same runs: remember the last
+    // (run head -> root) pair per lookup class so a straight edge costs one parent[] load.
+    struct Memo { int head, root; };
+    Memo mo{-1, 0}, ml{-1, 0}, mb{-1, 0}, mr{-1, 0}, mt{-1, 0};
+    auto root_of = [&](Memo &m, int head) -> int {
+        if (head != m.head) { m.head = head; m.root = parent[head]; }
+        return m.root;
+    };
 
     int label = -1;
     long long s00 = 0, s10 = 0, s01 = 0;
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_
         cand &= cand - 1;
         const int x = w * 64 + i;
         const u64 bit = 1ull << i;
-        const int lab = parent[run_head_w(g, Tc, cc, y, w, i)];
+        const int lab = root_of(mo, run_head_w(g, Tc, cc, y, w, i));
         if (lab != label) {
             if (label >= 0 && (s00 | s10 | s01)) {
                 atomicAdd((unsigned long long *)&acc[(size_t)label * 3], (unsigned long long)s00);
@@ -390,22 +399,28 @@ __global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_
             const int d = x * qy - qx * y;                                            \
             s00 += d; s10 += (long long)d * (x + qx); s01 += (long long)d * (y + qy); \
         }
-        if (!(L & bit) && parent[run_head(g, trans, carry, y, x - 1)] == 0) {        // left
-            e = true;
-            if (DL & bit) { qx = x - 1; qy = y + 1; } else if (D & bit) { qx = x; qy = y + 1; } else e = false;
-            OAT_EDGE()
+        if (!(L & bit)) {                                                             // left
+            const int h = i > 0 ? run_head_w(g, Tc, cc, y, w, i - 1) : run_head(g, trans, carry, y, x - 1);
+            if (root_of(ml, h) == 0) {
+                e = true;
+                if (DL & bit) { qx = x - 1; qy = y + 1; } else if (D & bit) { qx = x; qy = y + 1; } else e = false;
+                OAT_EDGE()
+            }
         }
-        if (!(D & bit) && parent[run_head(g, trans, carry, y + 1, x)] == 0) {        // bottom
+        if (!(D & bit) && root_of(mb, run_head_w(g, Td, cd, y + 1, w, i)) == 0) {    // bottom
             e = true;
             if (DR & bit) { qx = x + 1; qy = y + 1; } else if (R & bit) { qx = x + 1; qy = y; } else e = false;
             OAT_EDGE()
         }
-        if (!(R & bit) && parent[run_head(g, trans, carry, y, x + 1)] == 0) {        // right
-            e = true;
-            if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
-            OAT_EDGE()
+        if (!(R & bit)) {                                                             // right
+            const int h = i < 63 ? run_head_w(g, Tc, cc, y, w, i + 1) : run_head(g, trans, carry, y, x + 1);
+            if (root_of(mr, h) == 0) {
+                e = true;
+                if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
+                OAT_EDGE()
+            }
         }
-        if (!(U & bit) && parent[run_head(g, trans, carry, y - 1, x)] == 0) {        // top
+        if (!(U & bit) && root_of(mt, run_head_w(g, Tu, cu, y - 1, w, i)) == 0) {    // top
             e = true;
             if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
             OAT_EDGE()

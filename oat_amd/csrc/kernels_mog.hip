@@ -33,6 +33,7 @@ struct PxModel {
     float m[kMaxMix][3];
 };
 
+template <int CH>
 __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // exchange modes i and i-1
 {
     dvm |= (3u << (i - 1));
@@ -40,13 +41,16 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // e
     t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
     t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
+    for (int c = 0; c < CH; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
 }
 
 // MOG2Invoker's per-pixel body (OpenCV 3.1.0 bgfg_gaussmix2.cpp) on a register
 // resident mixture.  Returns the foreground-mask value {0, shadowVal, 255}.
 // dvm: bit k set when mode k's variance/mean registers were written; wchg: weights may differ
 // from what was loaded (false only when alpha == 0 and the renormalisation was by exactly 1).
+// CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
+// 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
+template <int CH>
 __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, float x1, float x2,
                                           const MogParams &P, float alphaT, float alpha1, float prune,
                                           unsigned &dvm, bool &wchg)
@@ -63,9 +67,9 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
             if (!fits) {
                 const float var = s.v[mode];
                 const float d0 = s.m[mode][0] - x0;
-                const float d1 = s.m[mode][1] - x1;
-                const float d2 = s.m[mode][2] - x2;
-                const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+                const float d1 = CH == 3 ? s.m[mode][1] - x1 : 0.f;
+                const float d2 = CH == 3 ? s.m[mode][2] - x2 : 0.f;
+                const float dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
                 if (total < P.TB && dist2 < P.Tb * var) background = true;
                 if (dist2 < P.Tg * var) {
                     fits = true;
@@ -73,8 +77,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
                     weight += alphaT;
                     const float k = alphaT / weight;
                     s.m[mode][0] -= k * d0;
-                    s.m[mode][1] -= k * d1;
-                    s.m[mode][2] -= k * d2;
+                    if (CH == 3) { s.m[mode][1] -= k * d1; s.m[mode][2] -= k * d2; }
                     float varnew = var + k * (dist2 - var);
                     varnew = varnew > P.varMin ? varnew : P.varMin;
                     varnew = varnew < P.varMax ? varnew : P.varMax;
@@ -88,7 +91,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
                     for (int i = mode; i > 0; --i) {
                         if (moving) {
                             if (weight < s.w[i - 1]) moving = false;
-                            else swap_up(s, i, dvm);
+                            else swap_up<CH>(s, i, dvm);
                         }
                     }
                 }
@@ -120,7 +123,8 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
                 dvm |= (1u << i);
                 s.w[i] = first ? 1.f : alphaT;
                 s.v[i] = P.varInit;
-                s.m[i][0] = x0; s.m[i][1] = x1; s.m[i][2] = x2;
+                s.m[i][0] = x0;
+                if (CH == 3) { s.m[i][1] = x1; s.m[i][2] = x2; }
             }
         }
         bool moving = true;
@@ -128,7 +132,7 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
         for (int i = kMaxMix - 1; i > 0; --i) {
             if (moving && i <= nmodes - 1) {
                 if (alphaT < s.w[i - 1]) moving = false;
-                else swap_up(s, i, dvm);
+                else swap_up<CH>(s, i, dvm);
             }
         }
     }
@@ -143,16 +147,16 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
 #pragma unroll
         for (int mode = 0; mode < kMaxMix; ++mode) {
             if (!done && mode < nmodes) {
-                const float m0 = s.m[mode][0], m1 = s.m[mode][1], m2 = s.m[mode][2];
-                const float num = x0 * m0 + x1 * m1 + x2 * m2;
-                const float den = m0 * m0 + m1 * m1 + m2 * m2;
+                const float m0 = s.m[mode][0], m1 = CH == 3 ? s.m[mode][1] : 0.f, m2 = CH == 3 ? s.m[mode][2] : 0.f;
+                const float num = CH == 3 ? x0 * m0 + x1 * m1 + x2 * m2 : x0 * m0;
+                const float den = CH == 3 ? m0 * m0 + m1 * m1 + m2 * m2 : m0 * m0;
                 if (den == 0.f) {
                     done = true;
                 } else {
                     if (num <= den && num >= P.tau * den) {
                         const float a = num / den;
                         const float e0 = a * m0 - x0, e1 = a * m1 - x1, e2 = a * m2 - x2;
-                        const float dist2a = e0 * e0 + e1 * e1 + e2 * e2;
+                        const float dist2a = CH == 3 ? e0 * e0 + e1 * e1 + e2 * e2 : e0 * e0;
                         if (dist2a < P.Tb * s.v[mode] * a * a) { mask = P.shadowVal; done = true; }
                     }
                     if (!done) {
@@ -202,6 +206,7 @@ template <> struct VecOf<2> { typedef float2 F; typedef uchar2 B; };
 typedef VecOf<kPX>::F vecf;
 typedef VecOf<kPX>::B vecb;
 
+template <int CH>
 __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     __shared__ int sdiv[256];
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
     if (base >= g.P) return;                      // whole wave beyond the image (tail block)
 
     const size_t npx = (size_t)g.H * g.W;
-    const uint8_t *frame = a.frames + (size_t)s * npx * 3;
+    const uint8_t *frame = a.frames + (size_t)s * npx * CH;
     float *sbase = a.state + (size_t)s * mog_stream_floats(g.Palloc);
     float *st = sbase + mog_plane_off(g.Palloc, 0, base) + kPX * lane;     // plane 0 of this wave's tile
     const size_t PS = mog_plane_stride(g.Palloc);                           // plane k = st + k * PS
@@ -239,7 +244,11 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         *(vecf *)W[0] = *(const vecf *)(st);
         *(vecf *)V[0] = *(const vecf *)(st + (size_t)5 * PS);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) *(vecf *)M[0][c] = *(const vecf *)(st + (size_t)(10 + c) * PS);
+        for (int c = 0; c < CH; ++c) *(vecf *)M[0][c] = *(const vecf *)(st + (size_t)(10 + c) * PS);
+        if (CH == 1) {
+#pragma unroll
+            for (int j = 0; j < kPX; ++j) { M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < kPX; ++j) { W[0][j] = 0.f; V[0][j] = 0.f; M[0][0][j] = 0.f; M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
@@ -253,8 +262,12 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
             *(vecf *)W[k] = *(const vecf *)(st + (size_t)k * PS);
             *(vecf *)V[k] = *(const vecf *)(st + (size_t)(5 + k) * PS);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < CH; ++c)
                 *(vecf *)M[k][c] = *(const vecf *)(st + (size_t)(10 + 3 * k + c) * PS);
+            if (CH == 1) {
+#pragma unroll
+                for (int j = 0; j < kPX; ++j) { M[k][1][j] = 0.f; M[k][2][j] = 0.f; }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < kPX; ++j) {
@@ -272,9 +285,12 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         const int y = p / g.Wp;
         const int x = p - y * g.Wp;
         const bool valid = (p < g.P) && (x < g.W);
-        const size_t fi = ((size_t)y * g.W + x) * 3;
+        const size_t fi = ((size_t)y * g.W + x) * CH;
         int b = 0, gg = 0, r = 0;
-        if (valid) { b = frame[fi]; gg = frame[fi + 1]; r = frame[fi + 2]; }
+        if (valid) {
+            b = frame[fi];
+            if (CH == 3) { gg = frame[fi + 1]; r = frame[fi + 2]; }
+        }
 
         PxModel pm;
 #pragma unroll
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         int mask = 0;
         if (valid) {
             bool wc = false;
-            mask = mog2_pixel(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune, dvm, wc);
+            mask = mog2_pixel<CH>(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune, dvm, wc);
             wchg |= wc;
         }
         nmodes[j] = n;
@@ -300,12 +316,18 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         if (mask == 0) { b = 0; gg = 0; r = 0; }
         if (valid && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
         if (valid && a.out_bgr) {
-            uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * 3 + fi;
-            o[0] = (uint8_t)b; o[1] = (uint8_t)gg; o[2] = (uint8_t)r;
+            uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * CH + fi;
+            o[0] = (uint8_t)b;
+            if (CH == 3) { o[1] = (uint8_t)gg; o[2] = (uint8_t)r; }
         }
-        int hh, ss, vv;
-        bgr2hsv_px(b, gg, r, sdiv, hdiv, hh, ss, vv);
-        const bool thr = valid && in_range3(hh, ss, vv, a.rp);
+        bool thr;
+        if (CH == 3) {
+            int hh, ss, vv;
+            bgr2hsv_px(b, gg, r, sdiv, hdiv, hh, ss, vv);
+            thr = valid && in_range3(hh, ss, vv, a.rp);
+        } else {                                     // GREY chain: framefilt mog -> posidet thresh
+            thr = valid && b >= a.rp.lo[0] && b <= a.rp.hi[0];
+        }
         words[j] = __ballot(thr);
     }
 
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         if ((dvm >> k) & 1u) {
             *(vecf *)(st + (size_t)(5 + k) * PS) = *(const vecf *)V[k];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < CH; ++c)
                 *(vecf *)(st + (size_t)(10 + 3 * k + c) * PS) = *(const vecf *)M[k][c];
         }
     }
@@ -345,7 +367,8 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    hipLaunchKernelGGL(k_mog_fused, grid, dim3(256), 0, st, g, a, first_stream);
+    if (a.channels == 1) hipLaunchKernelGGL(k_mog_fused<1>, grid, dim3(256), 0, st, g, a, first_stream);
+    else hipLaunchKernelGGL(k_mog_fused<3>, grid, dim3(256), 0, st, g, a, first_stream);
 }
 
 // ------------------------------------------------------------ small kernels --
@@ -433,7 +456,7 @@ __device__ __forceinline__ uint8_t *count_elem(const Geom &g, float *sbase, uint
 #endif
 }
 
-__global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint8_t *nmodes, int nmix,
+__global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint8_t *nmodes, int nmix, int ch,
                                                       uint8_t *modes_used, float *weight, float *variance,
                                                       float *mean)
 {
@@ -445,13 +468,13 @@ __global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint
         for (int k = 0; k < nmix; ++k) {
             weight[i * nmix + k] = *state_elem(g, state, k, p);
             variance[i * nmix + k] = *state_elem(g, state, 5 + k, p);
-            for (int c = 0; c < 3; ++c)
-                mean[(i * nmix + k) * 3 + c] = *state_elem(g, state, 10 + 3 * k + c, p);
+            for (int c = 0; c < ch; ++c)
+                mean[(i * nmix + k) * ch + c] = *state_elem(g, state, 10 + 3 * k + c, p);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint8_t *nmodes, int nmix,
+__global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint8_t *nmodes, int nmix, int ch,
                                                       const uint8_t *modes_used, const float *weight,
                                                       const float *variance, const float *mean)
 {
@@ -463,23 +486,24 @@ __global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint
         for (int k = 0; k < nmix; ++k) {
             *state_elem(g, state, k, p) = weight[i * nmix + k];
             *state_elem(g, state, 5 + k, p) = variance[i * nmix + k];
-            for (int c = 0; c < 3; ++c)
-                *state_elem(g, state, 10 + 3 * k + c, p) = mean[(i * nmix + k) * 3 + c];
+            for (int c = 0; c < ch; ++c)
+                *state_elem(g, state, 10 + 3 * k + c, p) = mean[(i * nmix + k) * ch + c];
         }
     }
 }
 
-void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix,
+void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix, int channels,
                          uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_state_export, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, modes_used, weight,
+    hipLaunchKernelGGL(k_state_export, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, channels, modes_used, weight,
                        variance, mean);
 }
 
-void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix, const uint8_t *modes_used,
-                         const float *weight, const float *variance, const float *mean, hipStream_t st)
+void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix, int channels,
+                         const uint8_t *modes_used, const float *weight, const float *variance, const float *mean,
+                         hipStream_t st)
 {
-    hipLaunchKernelGGL(k_state_import, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, modes_used, weight,
+    hipLaunchKernelGGL(k_state_import, dim3(2048), dim3(256), 0, st, g, state, nmodes, nmix, channels, modes_used, weight,
                        variance, mean);
 }
 

@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,11 +27,13 @@ struct oatgpu_ctx {
     Geom g;
     hipStream_t stream = nullptr;   // stream A: uploads + the fused per-pixel kernel
     bool own_stream = false;
-    hipStream_t stream_b = nullptr; // stream B: morphology + blob analysis of the PREVIOUS frame, overlapped
+    hipStream_t stream_b[2] = {nullptr, nullptr}; // streams B0/B1: morphology + blob analysis of even/odd frames,
+                                                  // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[2] = {nullptr, nullptr};    // K1 of parity q finished (thr[q] is ready)
     hipEvent_t ev_back[2] = {nullptr, nullptr};  // back half of parity q finished (thr[q] may be rewritten)
     bool back_pending[2] = {false, false};
     unsigned long long frame_no = 0;
+    bool serial = false;
     std::string err;
 
     // device memory
@@ -39,8 +42,9 @@ struct oatgpu_ctx {
     uint8_t *frames = nullptr;     // staging [n][H*W*3]
     uint8_t *aux_a = nullptr;      // [H*W*3]
     uint8_t *aux_b = nullptr;      // [H*W*3]
-    BlobBuffers bb{};
+    BlobBuffers bb[2]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
     const u64 *last_morph = nullptr;
+    const u64 *last_fin = nullptr;
     ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
     ResultRec *res_dev = nullptr;  // device alias of res_host: kernels store results straight to the host
     std::vector<hipEvent_t> ring_ev;
@@ -81,7 +85,7 @@ extern "C" int oatgpu_default_config(oatgpu_config *c)
 {
     if (!c) return OATGPU_E_INVALID;
     memset(c, 0, sizeof *c);
-    c->device = 0; c->n_streams = 1; c->rows = 0; c->cols = 0; c->ring_depth = 4;
+    c->device = 0; c->n_streams = 1; c->rows = 0; c->cols = 0; c->ring_depth = 4; c->channels = 3;
     // cv::createBackgroundSubtractorMOG2() defaults (bgfg_gaussmix2.cpp)
     c->history = 500; c->nmixtures = 5; c->var_threshold = 16.f; c->background_ratio = 0.9f;
     c->var_threshold_gen = 9.f; c->var_init = 15.f; c->var_min = 4.f; c->var_max = 75.f;
@@ -134,14 +138,17 @@ static void free_all(oatgpu_ctx *c)
 {
     if (!c) return;
     hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
-    hipFree(c->bb.thr); hipFree(c->bb.tmp); hipFree(c->bb.morph); hipFree(c->bb.fin); hipFree(c->bb.trans);
-    hipFree(c->bb.carry); hipFree(c->bb.parent); hipFree(c->bb.acc); hipFree(c->bb.best); hipFree(c->bb.done);
+    hipFree(c->bb[0].thr);
+    for (auto &b : c->bb) {
+        hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
+        hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.best); hipFree(b.done);
+    }
     if (c->res_host) hipHostFree(c->res_host);
     for (int q = 0; q < 2; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
         if (c->ev_back[q]) hipEventDestroy(c->ev_back[q]);
     }
-    if (c->stream_b) hipStreamDestroy(c->stream_b);
+    for (auto sb : c->stream_b) if (sb) hipStreamDestroy(sb);
     for (auto e : c->ring_ev) hipEventDestroy(e);
     for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -153,6 +160,10 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (!cfg) { fail(nullptr, OATGPU_E_INVALID, "null config"); return nullptr; }
     if (cfg->rows < 1 || cfg->cols < 1 || cfg->n_streams < 1 || cfg->ring_depth < 1) {
         fail(nullptr, OATGPU_E_INVALID, "rows, cols, n_streams and ring_depth must be >= 1");
+        return nullptr;
+    }
+    if (cfg->channels != 1 && cfg->channels != 3) {
+        fail(nullptr, OATGPU_E_INVALID, "channels must be 3 (BGR) or 1 (GREY)");
         return nullptr;
     }
     if (cfg->nmixtures < 1 || cfg->nmixtures > kMaxMix) {
@@ -195,27 +206,32 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         // bandwidth-bound launches of stream A: give it the highest priority
         int least = 0, greatest = 0;
         if (ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-        ok = ok && hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, greatest) == hipSuccess;
+        for (auto &sb : c->stream_b)
+            ok = ok && hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, greatest) == hipSuccess;
     }
+    c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
     for (int q = 0; q < 2 && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_back[q], hipEventDisableTiming) == hipSuccess;
     }
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
-    A((void **)&c->frames, n * npx * 3);
+    A((void **)&c->frames, n * npx * cfg->channels);
     A((void **)&c->aux_a, npx * 3);
     A((void **)&c->aux_b, npx * 3);
-    A((void **)&c->bb.thr, 2 * n * NW * 8);
-    A((void **)&c->bb.tmp, n * NW * 8);
-    A((void **)&c->bb.morph, n * NW * 8);
-    A((void **)&c->bb.fin, n * NW * 8);
-    A((void **)&c->bb.trans, n * NW * 8);
-    A((void **)&c->bb.carry, n * (size_t)g.H * g.words * sizeof(int));
-    A((void **)&c->bb.parent, n * PA * sizeof(int));
-    A((void **)&c->bb.acc, n * PA * 3 * sizeof(long long));
-    A((void **)&c->bb.best, n * 8);
-    A((void **)&c->bb.done, n * sizeof(unsigned));
+    A((void **)&c->bb[0].thr, 2 * n * NW * 8);
+    c->bb[1].thr = c->bb[0].thr;
+    for (auto &b : c->bb) {
+        A((void **)&b.tmp, n * NW * 8);
+        A((void **)&b.morph, n * NW * 8);
+        A((void **)&b.fin, n * NW * 8);
+        A((void **)&b.trans, n * NW * 8);
+        A((void **)&b.carry, n * (size_t)g.H * g.words * sizeof(int));
+        A((void **)&b.parent, n * PA * sizeof(int));
+        A((void **)&b.acc, n * PA * 3 * sizeof(long long));
+        A((void **)&b.best, n * 8);
+        A((void **)&b.done, n * sizeof(unsigned));
+    }
     const size_t slots = (size_t)cfg->ring_depth + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
@@ -228,16 +244,19 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb.thr, 0, 2 * n * NW * 8, c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb[0].thr, 0, 2 * n * NW * 8, c->stream) != hipSuccess) ok = false;
+    for (auto &b : c->bb) {
+        if (ok && hipMemsetAsync(b.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
+        if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+    }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
         fail(nullptr, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         free_all(c);
         return nullptr;
     }
-    c->last_morph = c->bb.thr;
+    c->last_morph = c->bb[0].thr;
+    c->last_fin = c->bb[0].fin;
     return c;
 }
 
@@ -246,7 +265,7 @@ extern "C" void oatgpu_destroy(oatgpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->stream_b) hipStreamSynchronize(c->stream_b);
+    for (auto sb : c->stream_b) if (sb) hipStreamSynchronize(sb);
     free_all(c);
 }
 
@@ -259,7 +278,7 @@ extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
@@ -270,7 +289,7 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
     return OATGPU_OK;
 }
 
@@ -308,7 +327,7 @@ static Rate mog_begin(oatgpu_ctx *c, int s, double learningRate)
 
 static u64 *thr_buf(oatgpu_ctx *c, int parity)
 {
-    return c->bb.thr + (size_t)parity * c->cfg.n_streams * (c->g.Palloc >> 6);
+    return c->bb[0].thr + (size_t)parity * c->cfg.n_streams * (c->g.Palloc >> 6);
 }
 
 // The single-stage calls are synchronous and share scratch with the pipelined path:
@@ -316,7 +335,7 @@ static u64 *thr_buf(oatgpu_ctx *c, int parity)
 static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
     c->back_pending[0] = c->back_pending[1] = false;
     return OATGPU_OK;
 }
@@ -324,7 +343,7 @@ static int quiesce(oatgpu_ctx *c)
 static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rate &r)
 {
     MogLaunch a{};
-    a.frames = frames; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = thr_buf(c, 0);
+    a.frames = frames; a.channels = c->cfg.channels; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = thr_buf(c, 0);
     a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0;
     a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
     a.mp = mogparams_of(c->cfg);
@@ -348,8 +367,9 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     rc = quiesce(c);
     if (rc) return rc;
     const size_t npx = (size_t)c->g.H * c->g.W;
-    uint8_t *slot = c->frames + (size_t)s * npx * 3;
-    HIPCHK(c, hipMemcpyAsync(slot, bgr_in, npx * 3, hipMemcpyHostToDevice, c->stream));
+    const size_t ch = c->cfg.channels;
+    uint8_t *slot = c->frames + (size_t)s * npx * ch;
+    HIPCHK(c, hipMemcpyAsync(slot, bgr_in, npx * ch, hipMemcpyHostToDevice, c->stream));
     const Rate r = mog_begin(c, s, lr);
     MogLaunch a = mog_launch_base(c, c->frames, r);
     a.out_base = s;
@@ -358,7 +378,7 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     launch_mog_fused(c->g, a, s, 1, c->stream);
     HIPCHK(c, hipGetLastError());
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, c->aux_a, npx, hipMemcpyDeviceToHost, c->stream));
-    if (bgr_out) HIPCHK(c, hipMemcpyAsync(bgr_out, c->aux_b, npx * 3, hipMemcpyDeviceToHost, c->stream));
+    if (bgr_out) HIPCHK(c, hipMemcpyAsync(bgr_out, c->aux_b, npx * ch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OATGPU_OK;
 }
@@ -410,19 +430,21 @@ static void to_position(const ResultRec &r, oatgpu_position *o)
 
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
 // the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
-static int back_half(oatgpu_ctx *c, const u64 *thr, int s0, int n, int slot, hipStream_t st, hipEvent_t ev_mid)
+static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int n, int slot, hipStream_t st,
+                     hipEvent_t ev_mid)
 {
     const Geom &g = c->g;
     const u64 *src = thr;
     if (c->cfg.erode > 1) {
-        launch_morph(g, src, c->bb.tmp, c->cfg.erode, true, s0, n, st);
-        src = c->bb.tmp;
+        launch_morph(g, src, bb.tmp, c->cfg.erode, true, s0, n, st);
+        src = bb.tmp;
     }
     if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, st));
     const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-    c->last_morph = dil ? c->bb.morph : src;
+    c->last_morph = dil ? bb.morph : src;
+    c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, c->bb, src, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
+    launch_blob(g, bb, src, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
     HIPCHK(c, hipGetLastError());
     return OATGPU_OK;
 }
@@ -441,7 +463,7 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
     RangeParams rp = range_of(c->cfg);
     launch_inrange_bits(g, c->aux_a, channels, rp, thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
     const int slot = c->cfg.ring_depth;   // the extra slot
-    rc = back_half(c, thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
+    rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
     if (rc) return rc;
     c->frame_no = 0;                       // next pipelined frame starts on parity 0 again
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -464,7 +486,7 @@ static void prof_fold(oatgpu_ctx *c)
 {
     if (!c->prof_used) return;
     hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->stream_b);
+    for (auto sb : c->stream_b) hipStreamSynchronize(sb);
     for (size_t i = 0; i < c->prof_used; ++i) {
         float a = 0, b = 0, d = 0, t = 0;
         ProfStep &p = c->prof_steps[i];
@@ -486,7 +508,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     const int n = c->cfg.n_streams;
     const int slot = (c->ring_head + c->ring_count) % c->cfg.ring_depth;
     const int q = (int)(c->frame_no & 1);           // which threshold-bit buffer this frame uses
-    hipStream_t A = c->stream, B = c->stream_b;
+    hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
 
     ProfStep *ps = nullptr;
     if (c->prof) {
@@ -527,7 +549,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     // Stream B: morphology + blob analysis of this frame.
     HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
     if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
-    int rc = back_half(c, thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
+    int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
     if (rc) return rc;
     if (ps) {
         if (c->cfg.erode <= 1) { /* e[3] was recorded right after e[2] */ }
@@ -571,7 +593,7 @@ extern "C" int oatgpu_track_batch(oatgpu_ctx *c, const uint8_t *const *frames_ho
     if (!c || !frames_host || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     if (n != c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "expected %d frames, got %d", c->cfg.n_streams, n);
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const size_t fb = (size_t)c->g.H * c->g.W * 3;
+    const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels;
     for (int s = 0; s < n; ++s) {
         if (!frames_host[s]) return fail(c, OATGPU_E_INVALID, "null frame %d", s);
         HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)s * fb, frames_host[s], fb, hipMemcpyHostToDevice, c->stream));
@@ -592,7 +614,7 @@ extern "C" int oatgpu_read_mask(oatgpu_ctx *c, int32_t s, int32_t which, uint8_t
     const u64 *last_thr = thr_buf(c, c->frame_no ? (int)((c->frame_no - 1) & 1) : 0);
     const u64 *base = which == OATGPU_TAP_THRESHOLD ? last_thr
                     : which == OATGPU_TAP_MORPH ? c->last_morph
-                    : which == OATGPU_TAP_FINAL ? c->bb.fin : nullptr;
+                    : which == OATGPU_TAP_FINAL ? c->last_fin : nullptr;
     if (!base) return fail(c, OATGPU_E_INVALID, "unknown tap %d", which);
     const size_t npx = (size_t)c->g.H * c->g.W;
     launch_unpack_bits(c->g, base + (size_t)s * (c->g.Palloc >> 6), c->aux_b, c->stream);
@@ -611,19 +633,19 @@ extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_use
     rc = quiesce(c);
     if (rc) return rc;
     const Geom &g = c->g;
-    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures;
+    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures, mb = 4 * (size_t)c->cfg.channels;
     uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
     HIPCHK(c, hipMalloc((void **)&d_mu, npx));
     HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
     HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * 12));
+    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * mb));
     launch_state_export(g, c->state + (size_t)s * mog_stream_floats(g.Palloc), c->nmodes + (size_t)s * g.Palloc, (int)k,
-                        d_mu, d_w, d_v, d_m, c->stream);
+                        c->cfg.channels, d_mu, d_w, d_v, d_m, c->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && modes_used) e = hipMemcpyAsync(modes_used, d_mu, npx, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && weight) e = hipMemcpyAsync(weight, d_w, npx * k * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && variance) e = hipMemcpyAsync(variance, d_v, npx * k * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && mean) e = hipMemcpyAsync(mean, d_m, npx * k * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && mean) e = hipMemcpyAsync(mean, d_m, npx * k * mb, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_mu); hipFree(d_w); hipFree(d_v); hipFree(d_m);
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state export failed: %s", hipGetErrorString(e));
@@ -640,19 +662,19 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
         return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const Geom &g = c->g;
-    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures;
+    const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures, mb = 4 * (size_t)c->cfg.channels;
     uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
     HIPCHK(c, hipMalloc((void **)&d_mu, npx));
     HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
     HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * 12));
+    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * mb));
     hipError_t e = hipMemcpyAsync(d_mu, modes_used, npx, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_w, weight, npx * k * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_v, variance, npx * k * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_m, mean, npx * k * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m, mean, npx * k * mb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         launch_state_import(g, c->state + (size_t)s * mog_stream_floats(g.Palloc), c->nmodes + (size_t)s * g.Palloc, (int)k,
-                            d_mu, d_w, d_v, d_m, c->stream);
+                            c->cfg.channels, d_mu, d_w, d_v, d_m, c->stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -92,7 +92,8 @@ struct RangeParams {
 };
 
 struct MogLaunch {
-    const uint8_t *frames;   // [n][H*W*3] packed BGR
+    const uint8_t *frames;   // [n][H*W*channels] packed BGR (3) or GREY (1)
+    int channels;
     float *state;            // [n][mog_stream_floats(Palloc)]
     uint8_t *nmodes;         // planar layout only: [n][Palloc] counters (same lane-interleaved slots)
     u64 *thr_bits;           // [n][Palloc/64] or nullptr
@@ -114,9 +115,9 @@ void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, cons
 void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st);
 // model checkpoint: logical (OpenCV AoS) <-> device planes
 // state / nmodes point at ONE stream's model
-void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix,
+void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix, int channels,
                          uint8_t *modes_used, float *weight, float *variance, float *mean, hipStream_t st);
-void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix,
+void launch_state_import(const Geom &g, float *state, uint8_t *nmodes, int nmix, int channels,
                          const uint8_t *modes_used, const float *weight, const float *variance,
                          const float *mean, hipStream_t st);
 

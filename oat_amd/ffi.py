@@ -19,7 +19,7 @@ class OatGpuError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("n_streams", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
-        ("ring_depth", C.c_int32),
+        ("ring_depth", C.c_int32), ("channels", C.c_int32),
         ("history", C.c_int32), ("nmixtures", C.c_int32),
         ("var_threshold", C.c_float), ("background_ratio", C.c_float), ("var_threshold_gen", C.c_float),
         ("var_init", C.c_float), ("var_min", C.c_float), ("var_max", C.c_float), ("ct", C.c_float),

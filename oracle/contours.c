@@ -23,6 +23,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -400,17 +401,86 @@ void oat_detect_thresh(const uint8_t *grey, int rows, int cols, const oat_hsv_pa
     free(thr);
 }
 
+/* Row-parallel helper for the element-wise / stencil stages of the CPU baseline (what OpenCV's
+ * parallel_for_ does for cvtColor / inRange / morphology).  Results do not depend on nthreads. */
+typedef struct {
+    int stage;                 /* 0: bgr2hsv + inRange, 1: erode/dilate row pass, 2: column pass */
+    const uint8_t *src; uint8_t *dst; uint8_t *aux;
+    int rows, cols, k, is_erode, y0, y1;
+    const int *lo, *hi;
+} chain_job;
+
+static void *chain_worker(void *arg)
+{
+    chain_job *j = (chain_job *)arg;
+    const int cols = j->cols;
+    if (j->stage == 0) {
+        size_t off = (size_t)j->y0 * cols, n = (size_t)(j->y1 - j->y0) * cols;
+        if (j->k == 1) {          /* GREY chain: framefilt mog -> posidet thresh (no colour conversion) */
+            oat_inrange1(j->src + off, n, j->lo[0], j->hi[0], j->dst + off);
+            return NULL;
+        }
+        oat_bgr2hsv(j->src + off * 3, j->aux + off * 3, n);
+        oat_inrange3(j->aux + off * 3, n, j->lo, j->hi, j->dst + off);
+        return NULL;
+    }
+    const int k = j->k, a = k / 2;
+    const uint8_t border = j->is_erode ? 255 : 0;
+    for (int y = j->y0; y < j->y1; y++)
+        for (int x = 0; x < cols; x++) {
+            uint8_t acc = border;
+            for (int t = 0; t < k; t++) {
+                uint8_t v;
+                if (j->stage == 1) { int xx = x - a + t; v = (xx < 0 || xx >= cols) ? border : j->src[(size_t)y * cols + xx]; }
+                else { int yy = y - a + t; v = (yy < 0 || yy >= j->rows) ? border : j->src[(size_t)yy * cols + x]; }
+                if (t == 0) acc = v;
+                else if (j->is_erode ? (v < acc) : (v > acc)) acc = v;
+            }
+            j->dst[(size_t)y * cols + x] = acc;
+        }
+    return NULL;
+}
+
+static void chain_parallel(chain_job proto, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if (nthreads > proto.rows) nthreads = proto.rows;
+    pthread_t th[256];
+    chain_job jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = proto;
+        jobs[t].y0 = (int)((long)proto.rows * t / nthreads);
+        jobs[t].y1 = (int)((long)proto.rows * (t + 1) / nthreads);
+        if (nthreads == 1) { chain_worker(&jobs[0]); return; }
+        pthread_create(&th[t], NULL, chain_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
+static void morph_mt(uint8_t *img, uint8_t *tmp, int rows, int cols, int k, int is_erode, int nthreads)
+{
+    if (k <= 1) return;
+    chain_job j = { 1, img, tmp, NULL, rows, cols, k, is_erode, 0, 0, NULL, NULL };
+    chain_parallel(j, nthreads);
+    j.stage = 2; j.src = tmp; j.dst = img;
+    chain_parallel(j, nthreads);
+}
+
 void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double learning_rate,
                     const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
                     oat_detection *out, int nthreads)
 {
     size_t n = (size_t)rows * cols;
-    uint8_t *mask = scratch;            /* n   */
+    uint8_t *mask = scratch;            /* n   (reused as the morphology temporary) */
     uint8_t *hsv = scratch + n;         /* 3n  */
     uint8_t *thr = scratch + 4 * n;     /* n   */
     oat_mog2_filter_mt(m, frame, mask, learning_rate, nthreads);
-    oat_bgr2hsv(frame, hsv, n);
     int lo[3] = { p->h_lo, p->s_lo, p->v_lo }, hi[3] = { p->h_hi, p->s_hi, p->v_hi };
-    oat_inrange3(hsv, n, lo, hi, thr);
-    morph_and_sift(thr, rows, cols, p, thr_out, out);
+    chain_job j = { 0, frame, thr, hsv, rows, cols, oat_mog2_channels(m), 0, 0, 0, lo, hi };   /* k carries the channel count for stage 0 */
+    chain_parallel(j, nthreads);
+    if (p->erode > 0) morph_mt(thr, mask, rows, cols, p->erode, 1, nthreads);
+    if (p->dilate > 0) morph_mt(thr, mask, rows, cols, p->dilate, 0, nthreads);
+    if (thr_out) memcpy(thr_out, thr, n);
+    oat_sift_contours(thr, rows, cols, p->min_area, p->max_area, out);
 }

@@ -73,6 +73,7 @@ void oat_mog2_destroy(oat_mog2 *m)
 }
 
 int oat_mog2_nframes(const oat_mog2 *m) { return m->nframes; }
+int oat_mog2_channels(const oat_mog2 *m) { return m->ch; }
 const uint8_t *oat_mog2_modes_used(const oat_mog2 *m) { return m->modes_used; }
 
 void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float *mean)

@@ -71,6 +71,7 @@ void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learn
 
 /* State inspection (tests / parity): per pixel, `nmixtures` entries. */
 int oat_mog2_nframes(const oat_mog2 *m);
+int oat_mog2_channels(const oat_mog2 *m);
 const uint8_t *oat_mog2_modes_used(const oat_mog2 *m);         /* rows*cols */
 /* weight[p*nmix+k], variance[p*nmix+k], mean[(p*nmix+k)*ch+c] */
 void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float *mean);
@@ -163,8 +164,9 @@ void oat_detect_hsv(const uint8_t *hsv, int rows, int cols, const oat_hsv_params
 void oat_detect_thresh(const uint8_t *grey, int rows, int cols, const oat_hsv_params *p,
                        uint8_t *thr_out, oat_detection *out);
 
-/* Whole chain for one BGR frame: mog filter -> BGR2HSV -> detect_hsv.
- * (frameserve -> framefilt mog -> framefilt col -C HSV -> posidet hsv.)
+/* Whole chain for one frame.  3-channel model: mog filter -> BGR2HSV -> detect_hsv
+ * (frameserve -> framefilt mog -> framefilt col -C HSV -> posidet hsv).  1-channel model:
+ * mog filter -> detect_thresh with [h_lo,h_hi] (frameserve -C GREY -> framefilt mog -> posidet thresh).
  * frame is consumed (modified).  scratch must hold rows*cols*5 bytes.
  * nthreads > 1 row-parallelises the per-pixel stages. */
 void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double learning_rate,

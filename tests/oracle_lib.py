@@ -235,7 +235,7 @@ def detect_thresh(grey, p):
 
 
 def chain_step(mog, frame, lr, p, nthreads=1):
-    """mog filter -> bgr2hsv -> detect_hsv on one frame (frame is not modified)."""
+    """mog filter -> (bgr2hsv ->) detect on one frame (frame is not modified); GREY when mog.ch == 1."""
     frame = _c(frame).copy()
     n = mog.rows * mog.cols
     scratch = np.empty(5 * n, np.uint8)

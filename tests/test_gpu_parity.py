@@ -394,6 +394,55 @@ def test_enqueue_collect_order_and_ring_limits(A):
     assert ei.value.code == ffi.E_RING_EMPTY
 
 
+@pytest.mark.parametrize("rate", [0.0, 0.02])
+def test_grey_mog2_parity(A, rate):
+    """framefilt mog on GREY frames (MOG2's generic-channel path), mask + model."""
+    rows, cols = 41, 150
+    rng = np.random.default_rng(77)
+    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=rate, channels=1)
+    o = O.Mog2(rows, cols, 1)
+    base = rng.integers(0, 256, (rows, cols)).astype(np.int16)
+    alt = rng.integers(0, 256, (rows, cols)).astype(np.int16)
+    for t in range(80):
+        f = np.where(rng.random((rows, cols)) < 0.25, alt, base) + rng.integers(-10, 11, (rows, cols))
+        if t % 19 == 4:
+            f[:] = rng.integers(0, 256, (rows, cols))
+        f = np.clip(f, 0, 255).astype(np.uint8)
+        assert (g.apply(f) == o.apply(f, rate)).all(), t
+        if t % 20 == 19 or t < 2:
+            _same_state(g.mog_state(), o.state(), t)
+    f = np.clip(base + rng.integers(-30, 31, (rows, cols)), 0, 255).astype(np.uint8)
+    want, _ = o.filter(f, rate)
+    assert (g.filter(f.copy()) == want).all()
+
+
+def test_grey_chain_mog_then_thresh(A):
+    """frameserve -C GREY -> framefilt mog -> posidet thresh, fused on the GPU vs the oracle chain."""
+    rows, cols, n = 200, 320, 2
+    rng = np.random.default_rng(9)
+    hp = A.HotPath(rows, cols, n_streams=n, channels=1, adaptation_coeff=0.01, h_thresh=(180, 256), erode=2,
+                   dilate=5, area=(10.0, 1e5))
+    p = O.hsv_params(h_lo=180, h_hi=256, erode=2, dilate=5, min_area=10.0, max_area=1e5)
+    orcs = [O.Mog2(rows, cols, 1) for _ in range(n)]
+    base = [rng.integers(60, 120, (rows, cols)).astype(np.int16) for _ in range(n)]
+    hits = 0
+    for t in range(25):
+        frames = []
+        for s in range(n):
+            f = np.clip(base[s] + rng.integers(-5, 6, (rows, cols)), 0, 255).astype(np.uint8)
+            if t > 0:
+                x, y = 20 + 9 * t + 30 * s, 30 + 5 * t
+                f[y:y + 18, x:x + 25] = 230
+            frames.append(f)
+        got = hp.track(frames)
+        for s in range(n):
+            want, thr = O.chain_step(orcs[s], frames[s], 0.01, p)
+            assert (hp.read_mask(1, s) == thr).all(), (t, s)
+            _same_detection(got[s], want, (t, s))
+            hits += got[s].position_valid
+    assert hits >= 40
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135
