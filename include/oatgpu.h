@@ -99,6 +99,9 @@ typedef struct oatgpu_profile {
     double morph_ms;           /* erode + dilate                              */
     double blob_ms;            /* labelling + contour sums + selection        */
     double total_ms;           /* first event to last event of each step      */
+    double event_pair_ms;      /* calibration: elapsed time of an EMPTY event pair on the
+                                  same HIP stream (what each *_ms above contains per step
+                                  besides kernel execution); measured at profile_enable */
 } oatgpu_profile;
 
 typedef struct oatgpu_ctx oatgpu_ctx;
@@ -191,6 +194,8 @@ int oatgpu_mog_set_state(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *mode
                          int32_t nframes);
 
 /* ---- measurement ---- */
+/* on = 0: off; on = 1: time every step; on = N > 1: time every Nth step (each timed step costs
+ * five hipEventRecord calls, ~20 us of host time -- sample when the host is the bottleneck). */
 int oatgpu_profile_enable(oatgpu_ctx *ctx, int32_t on);
 int oatgpu_profile_read(oatgpu_ctx *ctx, oatgpu_profile *out);   /* synchronises */
 int oatgpu_profile_reset(oatgpu_ctx *ctx);

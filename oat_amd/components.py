@@ -232,8 +232,9 @@ class HotPath(_Context):
     def synchronize(self):
         self._chk(self.lib.oatgpu_synchronize(self.ctx))
 
-    def profile(self, on=True):
-        self._chk(self.lib.oatgpu_profile_enable(self.ctx, 1 if on else 0))
+    def profile(self, every=1):
+        """every = 0/False: off; 1/True: time every step; N: time every Nth step."""
+        self._chk(self.lib.oatgpu_profile_enable(self.ctx, int(every)))
 
     def profile_reset(self):
         self._chk(self.lib.oatgpu_profile_reset(self.ctx))
@@ -241,4 +242,5 @@ class HotPath(_Context):
     def profile_read(self):
         p = ffi.Profile()
         self._chk(self.lib.oatgpu_profile_read(self.ctx, C.byref(p)))
-        return dict(steps=p.steps, mog_ms=p.mog_ms, morph_ms=p.morph_ms, blob_ms=p.blob_ms, total_ms=p.total_ms)
+        return dict(steps=p.steps, mog_ms=p.mog_ms, morph_ms=p.morph_ms, blob_ms=p.blob_ms, total_ms=p.total_ms,
+                    event_pair_ms=p.event_pair_ms)

@@ -465,15 +465,17 @@ __global__ __launch_bounds__(256) void k_select(Geom g, BlobBuffers b, double mi
                 atomicMax((unsigned long long *)&b.best[s], (mag << 32) | (u64)(unsigned)h);
         }
     }
+    // Hand-off to the last-arriving workgroup.  Everything it reads that THIS kernel wrote is
+    // written and read with agent-scope atomics (best[] via atomicMax / atomic load, the arrival
+    // counter): every wave drains its atomics (vmcnt) before the workgroup arrives, so no
+    // release/acquire fence -- and no L2 write-back per workgroup -- is needed.  acc[] and
+    // parent[] come from earlier kernels.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(&b.done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (prev == gridDim.x - 1) ? 1 : 0;
         if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const u64 key = __hip_atomic_load((unsigned long long *)&b.best[s], __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
             ResultRec r;

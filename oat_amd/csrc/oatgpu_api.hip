@@ -30,10 +30,13 @@ struct oatgpu_ctx {
     hipStream_t stream_b[2] = {nullptr, nullptr}; // streams B0/B1: morphology + blob analysis of even/odd frames,
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[2] = {nullptr, nullptr};    // K1 of parity q finished (thr[q] is ready)
-    hipEvent_t ev_back[2] = {nullptr, nullptr};  // back half of parity q finished (thr[q] may be rewritten)
-    bool back_pending[2] = {false, false};
-    unsigned long long frame_no = 0;
+    hipEvent_t last_back[2] = {nullptr, nullptr}; // ring event of the last back half that read thr[q] / bb[q]
+    unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
+    int ring_slots = 0;                               // internal ring size: ring_depth rounded up to even
     bool serial = false;
+    bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
+    std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
+    int last_q = 0;
     std::string err;
 
     // device memory
@@ -48,15 +51,18 @@ struct oatgpu_ctx {
     ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
     ResultRec *res_dev = nullptr;  // device alias of res_host: kernels store results straight to the host
     std::vector<hipEvent_t> ring_ev;
-    int ring_head = 0, ring_count = 0;
+    int ring_count = 0;
 
     std::vector<int> nframes;      // per camera stream
 
     // profiling
     bool prof = false;
+    int prof_every = 1;            // sample every Nth step (event records cost ~4 us of host time each)
+    unsigned long long prof_tick = 0;
     std::vector<ProfStep> prof_steps;
     size_t prof_used = 0;
     oatgpu_profile prof_sum{};
+    double event_pair_ms = 0.0;
 };
 
 static int fail(oatgpu_ctx *c, int code, const char *fmt, ...)
@@ -146,8 +152,8 @@ static void free_all(oatgpu_ctx *c)
     if (c->res_host) hipHostFree(c->res_host);
     for (int q = 0; q < 2; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
-        if (c->ev_back[q]) hipEventDestroy(c->ev_back[q]);
     }
+    for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto sb : c->stream_b) if (sb) hipStreamDestroy(sb);
     for (auto e : c->ring_ev) hipEventDestroy(e);
     for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
@@ -210,9 +216,12 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
             ok = ok && hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
+    // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
+    // six plain launches on MI355X / ROCm 7.2 (profiles/r01_d_*): opt-in only.
+    c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
+    c->ring_slots = (cfg->ring_depth + 1) / 2 * 2;    // even, so that slot parity == frame parity
     for (int q = 0; q < 2 && ok; ++q) {
-        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_back[q], hipEventDisableTiming) == hipSuccess;
+        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess;
     }
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
@@ -232,12 +241,13 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         A((void **)&b.best, n * 8);
         A((void **)&b.done, n * sizeof(unsigned));
     }
-    const size_t slots = (size_t)cfg->ring_depth + 1;
+    const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
     if (ok && hipHostGetDevicePointer((void **)&c->res_dev, c->res_host, 0) != hipSuccess) ok = false;
     if (ok) {
-        c->ring_ev.resize(cfg->ring_depth);
+        c->ring_ev.resize(c->ring_slots);
+        c->back_graph.assign(c->ring_slots, nullptr);
         for (auto &e : c->ring_ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
     }
@@ -293,6 +303,8 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
     return OATGPU_OK;
 }
 
+static int quiesce(oatgpu_ctx *c);
+
 extern "C" int oatgpu_set_detector(oatgpu_ctx *c, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
                                    int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
                                    double min_area, double max_area)
@@ -303,7 +315,10 @@ extern "C" int oatgpu_set_detector(oatgpu_ctx *c, int32_t h_lo, int32_t h_hi, in
     k.erode = erode; k.dilate = dilate; k.min_area = min_area; k.max_area = max_area;
     int rc = check_detector(c, k);
     if (rc) return rc;
+    rc = quiesce(c);
+    if (rc) return rc;
     c->cfg = k;
+    for (auto &ge : c->back_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // parameters are baked in
     return OATGPU_OK;
 }
 
@@ -336,7 +351,7 @@ static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
-    c->back_pending[0] = c->back_pending[1] = false;
+    c->last_back[0] = c->last_back[1] = nullptr;
     return OATGPU_OK;
 }
 
@@ -462,10 +477,10 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
     HIPCHK(c, hipMemcpyAsync(c->aux_a, in, npx * channels, hipMemcpyHostToDevice, c->stream));
     RangeParams rp = range_of(c->cfg);
     launch_inrange_bits(g, c->aux_a, channels, rp, thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
-    const int slot = c->cfg.ring_depth;   // the extra slot
+    const int slot = c->ring_slots;       // the extra slot
     rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
     if (rc) return rc;
-    c->frame_no = 0;                       // next pipelined frame starts on parity 0 again
+    c->last_q = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
     return OATGPU_OK;
@@ -500,18 +515,34 @@ static void prof_fold(oatgpu_ctx *c)
     c->prof_used = 0;
 }
 
+// Capture the back half of ring slot `slot` (buffers of parity slot & 1, result record of that slot)
+// into an executable graph: six dependent launches become one hipGraphLaunch of host work.
+static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
+{
+    const int q = slot & 1;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(B, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
+    const int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, c->cfg.n_streams, slot, B, nullptr);
+    const hipError_t e = hipStreamEndCapture(B, &graph);
+    if (rc != OATGPU_OK || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); return nullptr; }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+    hipGraphDestroy(graph);
+    return exec;
+}
+
 extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, double lr)
 {
     if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
-    const int slot = (c->ring_head + c->ring_count) % c->cfg.ring_depth;
-    const int q = (int)(c->frame_no & 1);           // which threshold-bit buffer this frame uses
+    const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
+    const int q = slot & 1;                          // threshold-bit buffer / scratch set / stream of this frame
     hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
 
     ProfStep *ps = nullptr;
-    if (c->prof) {
+    if (c->prof && (c->prof_tick++ % (unsigned long long)c->prof_every) == 0) {
         if (c->prof_used == c->prof_steps.size()) {
             if (c->prof_steps.size() >= 1024) prof_fold(c);
             else {
@@ -523,10 +554,10 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         ps = &c->prof_steps[c->prof_used++];
     }
 
-    // Stream A: the fused per-pixel kernel of THIS frame may start while stream B is still
-    // analysing the previous frame's mask; it only has to wait for the back half that last
-    // read the threshold buffer it is about to overwrite (two frames ago).
-    if (c->back_pending[q]) HIPCHK(c, hipStreamWaitEvent(A, c->ev_back[q], 0));
+    // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
+    // analysing earlier frames' masks; it only has to wait for the back half that last read the
+    // threshold buffer it is about to overwrite (two frames ago).
+    if (c->last_back[q]) HIPCHK(c, hipStreamWaitEvent(A, c->last_back[q], 0));
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
     // every camera stream advances one frame; launches are batched while the streams share a
@@ -546,19 +577,28 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
     HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
 
-    // Stream B: morphology + blob analysis of this frame.
+    // Stream B[q]: morphology + blob analysis of this frame.
     HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
-    if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
-    int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
-    if (rc) return rc;
-    if (ps) {
-        if (c->cfg.erode <= 1) { /* e[3] was recorded right after e[2] */ }
-        HIPCHK(c, hipEventRecord(ps->e[4], B));
+    if (c->use_graph && !c->back_graph[slot]) {
+        c->back_graph[slot] = capture_back_half(c, slot, B);
+        if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
     }
+    if (c->use_graph && c->back_graph[slot]) {
+        if (ps) { HIPCHK(c, hipEventRecord(ps->e[2], B)); HIPCHK(c, hipEventRecord(ps->e[3], B)); }
+        HIPCHK(c, hipGraphLaunch(c->back_graph[slot], B));
+        const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+        c->last_morph = dil ? c->bb[q].morph : (c->cfg.erode > 1 ? c->bb[q].tmp : thr_buf(c, q));
+        c->last_fin = c->bb[q].fin;
+    } else {
+        if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
+        int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
+        if (rc) return rc;
+    }
+    if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
-    HIPCHK(c, hipEventRecord(c->ev_back[q], B));
-    c->back_pending[q] = true;
-    c->frame_no++;
+    c->last_back[q] = c->ring_ev[slot];
+    c->last_q = q;
+    c->enq_total++;
     c->ring_count++;
     return OATGPU_OK;
 }
@@ -567,11 +607,11 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
 {
     if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->ring_count == 0) return fail(c, OATGPU_E_RING_EMPTY, "nothing outstanding");
-    const int slot = c->ring_head;
+    const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
     HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
     for (int s = 0; s < c->cfg.n_streams; ++s) to_position(r[s], &out[s]);
-    c->ring_head = (c->ring_head + 1) % c->cfg.ring_depth;
+    c->col_total++;
     c->ring_count--;
     return OATGPU_OK;
 }
@@ -611,7 +651,7 @@ extern "C" int oatgpu_read_mask(oatgpu_ctx *c, int32_t s, int32_t which, uint8_t
     HIPCHK(c, hipSetDevice(c->cfg.device));
     rc = quiesce(c);
     if (rc) return rc;
-    const u64 *last_thr = thr_buf(c, c->frame_no ? (int)((c->frame_no - 1) & 1) : 0);
+    const u64 *last_thr = thr_buf(c, c->last_q);
     const u64 *base = which == OATGPU_TAP_THRESHOLD ? last_thr
                     : which == OATGPU_TAP_MORPH ? c->last_morph
                     : which == OATGPU_TAP_FINAL ? c->last_fin : nullptr;
@@ -690,7 +730,26 @@ extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
 {
     if (!c) return OATGPU_E_INVALID;
     if (!on) prof_fold(c);
+    if (on && !c->prof) {
+        // calibrate: what an event pair with NOTHING between it measures on stream A
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipEvent_t e0, e1;
+        HIPCHK(c, hipEventCreate(&e0));
+        HIPCHK(c, hipEventCreate(&e1));
+        float best = 1e30f;
+        for (int i = 0; i < 16; ++i) {
+            HIPCHK(c, hipEventRecord(e0, c->stream));
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(e1));
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) best = ms;
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        c->event_pair_ms = best < 1e29f ? best : 0.0;
+    }
     c->prof = on != 0;
+    c->prof_every = on > 1 ? on : 1;
+    c->prof_tick = 0;
     return OATGPU_OK;
 }
 extern "C" int oatgpu_profile_read(oatgpu_ctx *c, oatgpu_profile *out)
@@ -698,6 +757,7 @@ extern "C" int oatgpu_profile_read(oatgpu_ctx *c, oatgpu_profile *out)
     if (!c || !out) return OATGPU_E_INVALID;
     prof_fold(c);
     *out = c->prof_sum;
+    out->event_pair_ms = c->event_pair_ms;
     return OATGPU_OK;
 }
 extern "C" int oatgpu_profile_reset(oatgpu_ctx *c)

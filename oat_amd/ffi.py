@@ -37,7 +37,7 @@ class Position(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("steps", C.c_int64), ("mog_ms", C.c_double), ("morph_ms", C.c_double),
-                ("blob_ms", C.c_double), ("total_ms", C.c_double)]
+                ("blob_ms", C.c_double), ("total_ms", C.c_double), ("event_pair_ms", C.c_double)]
 
 
 E_RING_FULL = -4
