@@ -30,9 +30,9 @@ struct oatgpu_ctx {
     hipStream_t stream_b[2] = {nullptr, nullptr}; // streams B0/B1: morphology + blob analysis of even/odd frames,
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[2] = {nullptr, nullptr};    // K1 of parity q finished (thr[q] is ready)
-    hipEvent_t last_back[2] = {nullptr, nullptr}; // ring event of the last back half that read thr[q] / bb[q]
+    hipEvent_t last_back[4] = {nullptr, nullptr, nullptr, nullptr}; // ring event of the last back half that read thr[k]
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
-    int ring_slots = 0;                               // internal ring size: ring_depth rounded up to even
+    int ring_slots = 0;                               // internal ring size: ring_depth rounded up to a multiple of 4
     bool serial = false;
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
@@ -219,7 +219,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
     // six plain launches on MI355X / ROCm 7.2 (profiles/r01_d_*): opt-in only.
     c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
-    c->ring_slots = (cfg->ring_depth + 1) / 2 * 2;    // even, so that slot parity == frame parity
+    c->ring_slots = (cfg->ring_depth + 3) / 4 * 4;    // slot & 3 = threshold buffer, slot & 1 = scratch set / stream
     for (int q = 0; q < 2 && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess;
     }
@@ -228,7 +228,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     A((void **)&c->frames, n * npx * cfg->channels);
     A((void **)&c->aux_a, npx * 3);
     A((void **)&c->aux_b, npx * 3);
-    A((void **)&c->bb[0].thr, 2 * n * NW * 8);
+    A((void **)&c->bb[0].thr, 4 * n * NW * 8);       // four threshold-bit buffers: K1 runs up to 3 frames ahead
     c->bb[1].thr = c->bb[0].thr;
     for (auto &b : c->bb) {
         A((void **)&b.tmp, n * NW * 8);
@@ -254,7 +254,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb[0].thr, 0, 2 * n * NW * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb[0].thr, 0, 4 * n * NW * 8, c->stream) != hipSuccess) ok = false;
     for (auto &b : c->bb) {
         if (ok && hipMemsetAsync(b.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
@@ -351,7 +351,7 @@ static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
-    c->last_back[0] = c->last_back[1] = nullptr;
+    for (auto &e : c->last_back) e = nullptr;
     return OATGPU_OK;
 }
 
@@ -523,7 +523,7 @@ static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(B, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
-    const int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, c->cfg.n_streams, slot, B, nullptr);
+    const int rc = back_half(c, c->bb[q], thr_buf(c, slot & 3), 0, c->cfg.n_streams, slot, B, nullptr);
     const hipError_t e = hipStreamEndCapture(B, &graph);
     if (rc != OATGPU_OK || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); return nullptr; }
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
@@ -538,7 +538,8 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
     const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
-    const int q = slot & 1;                          // threshold-bit buffer / scratch set / stream of this frame
+    const int q = slot & 1;                          // scratch set / B stream of this frame
+    const int k = slot & 3;                          // threshold-bit buffer of this frame
     hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
 
     ProfStep *ps = nullptr;
@@ -556,8 +557,8 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
 
     // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
     // analysing earlier frames' masks; it only has to wait for the back half that last read the
-    // threshold buffer it is about to overwrite (two frames ago).
-    if (c->last_back[q]) HIPCHK(c, hipStreamWaitEvent(A, c->last_back[q], 0));
+    // threshold buffer it is about to overwrite (four frames ago).
+    if (c->last_back[k]) HIPCHK(c, hipStreamWaitEvent(A, c->last_back[k], 0));
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
     // every camera stream advances one frame; launches are batched while the streams share a
@@ -569,7 +570,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         int s1 = s0 + 1;
         while (s1 < n && memcmp(&rates[s1], &rates[s0], sizeof(Rate)) == 0) ++s1;
         MogLaunch a = mog_launch_base(c, (const uint8_t *)frames_dev, rates[s0]);
-        a.thr_bits = thr_buf(c, q);
+        a.thr_bits = thr_buf(c, k);
         launch_mog_fused(c->g, a, s0, s1 - s0, A);
         s0 = s1;
     }
@@ -587,17 +588,17 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         if (ps) { HIPCHK(c, hipEventRecord(ps->e[2], B)); HIPCHK(c, hipEventRecord(ps->e[3], B)); }
         HIPCHK(c, hipGraphLaunch(c->back_graph[slot], B));
         const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-        c->last_morph = dil ? c->bb[q].morph : (c->cfg.erode > 1 ? c->bb[q].tmp : thr_buf(c, q));
+        c->last_morph = dil ? c->bb[q].morph : (c->cfg.erode > 1 ? c->bb[q].tmp : thr_buf(c, k));
         c->last_fin = c->bb[q].fin;
     } else {
         if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
-        int rc = back_half(c, c->bb[q], thr_buf(c, q), 0, n, slot, B, ps ? ps->e[3] : nullptr);
+        int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, ps ? ps->e[3] : nullptr);
         if (rc) return rc;
     }
     if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
-    c->last_back[q] = c->ring_ev[slot];
-    c->last_q = q;
+    c->last_back[k] = c->ring_ev[slot];
+    c->last_q = k;
     c->enq_total++;
     c->ring_count++;
     return OATGPU_OK;

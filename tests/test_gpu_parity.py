@@ -443,6 +443,91 @@ def test_grey_chain_mog_then_thresh(A):
     assert hits >= 40
 
 
+@pytest.mark.parametrize("rate", [-1.0, 1.0])
+def test_mog2_auto_and_reinit_learning_rates(A, rate):
+    """learningRate < 0 -> 1/min(2n, history); learningRate >= 1 -> the model is re-initialised every frame."""
+    rows, cols = 24, 70
+    rng = np.random.default_rng(31)
+    g = A.BackgroundSubtractorMOG(rows, cols)
+    o = O.Mog2(rows, cols, 3)
+    base = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
+    for t in range(40):
+        f = np.clip(base + rng.integers(-20, 21, base.shape), 0, 255).astype(np.uint8)
+        assert (g.apply(f, learning_rate=rate) == o.apply(f, rate)).all(), t
+    _same_state(g.mog_state(), o.state())
+
+
+def test_mog2_non_default_parameters(A):
+    """3 mixtures, no shadow detection, tighter thresholds: the parameters are honoured, not baked in."""
+    rows, cols = 30, 64
+    over = dict(nmixtures=3, detect_shadows=0, var_threshold=10.0, var_threshold_gen=6.0, var_init=20.0,
+                var_min=2.0, var_max=60.0, background_ratio=0.8, ct=0.02)
+    rng = np.random.default_rng(32)
+    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=0.05, **over)
+    o = O.Mog2(rows, cols, 3, params=over)
+    cols6 = rng.integers(0, 256, (6, 3))
+    for t in range(100):
+        idx = rng.integers(0, 6, (rows, cols))
+        f = np.clip(cols6[idx] + rng.integers(-8, 9, (rows, cols, 3)), 0, 255).astype(np.uint8)
+        mg, mo = g.apply(f), o.apply(f, 0.05)
+        assert (mg == mo).all(), t
+        assert set(np.unique(mg)) <= {0, 255}              # no shadow value without shadow detection
+    _same_state(g.mog_state(), o.state())
+    assert o.state()[0].max() == 3
+
+
+def test_wide_frame_and_large_kernels(A):
+    """W > 4096 (row scan loops over 64-word chunks), W not a multiple of 64, k up to 63."""
+    rows, cols = 70, 4300
+    rng = np.random.default_rng(33)
+    det = A.SimpleThreshold(rows, cols, thresh=(1, 256))
+    for e, d, dens in [(0, 0, 0.5), (5, 63, 0.9), (63, 0, 0.9997), (9, 33, 0.97)]:
+        img = (rng.random((rows, cols)) < dens).astype(np.uint8) * 255
+        img[20:50, 3900:4250] = 255                          # a blob that crosses the 4096-px chunk boundary
+        det._set(erode=e, dilate=d)
+        got = det.detectPosition(img)
+        thr = img
+        if e:
+            thr = O.erode(thr, e)
+        if d:
+            thr = O.dilate(thr, d)
+        assert (det.read_mask(1) == thr).all(), (e, d)
+        _same_detection(got, O.sift_contours(thr), (e, d))
+    with pytest.raises(A.OatGpuError):
+        det._set(dilate=64)                                  # documented limit of the bit-packed morphology
+
+
+def test_batch_with_uneven_stream_histories_and_ring_depth_one(A):
+    """Streams whose models are at different frame counts cannot share a launch: results stay per-stream exact."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols, n = 120, 192, 3
+    win = disc_hsv_window()
+    hp = A.HotPath(rows, cols, n_streams=n, ring_depth=1, adaptation_coeff=-1.0, erode=0, dilate=5,
+                   area=(5.0, 1e5), **win)
+    hp.learning_coeff_ = -1.0        # auto rate depends on each stream's own frame count
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=0, dilate=5,
+                     min_area=5.0, max_area=1e5)
+    streams = [SyntheticStream(rows, cols, 10 + s, n_discs=1, radius=7) for s in range(n)]
+    orcs = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    # advance stream 1 alone by two frames through the single-stage entry point
+    pre = A.ffi.load()
+    for t in range(2):
+        f = streams[1].frame(t, with_discs=False)
+        out = np.empty_like(f)
+        hp._chk(pre.oatgpu_mog_filter(hp.ctx, 1, A.ffi.u8(f), A.ffi.u8(out), -1.0))
+        want, _ = orcs[1].filter(f, -1.0)
+        assert (out == want).all()
+    for t in range(12):
+        frames = [st.frame(t + 2, with_discs=t > 0) for st in streams]
+        got = hp.track(frames)
+        for s in range(n):
+            want, thr = O.chain_step(orcs[s], frames[s], -1.0, p)
+            assert (hp.read_mask(1, s) == thr).all(), (t, s)
+            _same_detection(got[s], want, (t, s))
+    for s in range(n):
+        _same_state(hp.mog_state(s), orcs[s].state(), s)
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135
