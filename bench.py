@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--input", default="device", choices=["device", "host"],
                     help="device: frames resident in HBM (the headline); host: pageable host frames through "
                          "oatgpu_track_batch, i.e. PCIe-inclusive (reported in DESIGN.md, never the headline)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
+                         "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -166,11 +169,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            local_rank = local_rank % max(ndev, 1)          # ranks may share a GPU in the smoke test
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
 
     wl = WORKLOADS[args.workload]
     rows, cols, ns = wl["rows"], wl["cols"], wl["streams"]
@@ -236,10 +245,10 @@ def main():
     hp.profile(0)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        found = torch.tensor([sum(p.position_valid for r in positions for p in r)], dtype=torch.int64, device=dev)
+        found = torch.tensor([sum(p.position_valid for r in positions for p in r)], dtype=torch.int64, device=red_dev)
         dist.all_reduce(found, op=dist.ReduceOp.SUM)
         n_found = int(found.item())
     else:

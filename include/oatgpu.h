@@ -126,6 +126,11 @@ int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_l
                         int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
                         double min_area, double max_area);
 
+/* `framefilt mask` fused in front of mog (src/framefilter/FrameMasker.cpp:71-75:
+ * frame.setTo(0, roi_mask == 0)): roi_mask is rows*cols bytes, nonzero = keep; NULL removes the
+ * mask of that stream.  Applies to oatgpu_mog_apply / _filter and the fused track calls. */
+int oatgpu_set_roi_mask(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *roi_mask);
+
 /* ---- stage-by-stage operators (host buffers), one call == one reference call ---- */
 
 /* cv::BackgroundSubtractorMOG2::apply(frame, mask, learning_rate)

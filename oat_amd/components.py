@@ -79,6 +79,14 @@ class _Context:
     def _chk(self, rc):
         ffi.check(self.lib, self.ctx, rc)
 
+    def set_roi_mask(self, mask, stream=0):
+        """framefilt mask fused in front of mog: mask (rows, cols) uint8, nonzero = keep; None clears."""
+        if mask is None:
+            self._chk(self.lib.oatgpu_set_roi_mask(self.ctx, stream, None))
+        else:
+            m = _frame(mask, (self.rows, self.cols))
+            self._chk(self.lib.oatgpu_set_roi_mask(self.ctx, stream, ffi.u8(m)))
+
     # -- taps ------------------------------------------------------------
     def read_mask(self, which=ffi.TAP_MORPH, stream=0):
         out = np.empty((self.rows, self.cols), np.uint8)

@@ -291,6 +291,12 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
             b = frame[fi];
             if (CH == 3) { gg = frame[fi + 1]; r = frame[fi + 2]; }
         }
+        // `framefilt mask` placed before mog (FrameMasker.cpp:71-75: frame.setTo(0, roi_mask == 0)):
+        // one bit per pixel, word j of this wave's tile covers pixel j of all 64 lanes.
+        if (a.roi_bits) {
+            const u64 rw = a.roi_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6) + j];
+            if (!((rw >> lane) & 1ull)) { b = 0; gg = 0; r = 0; }
+        }
 
         PxModel pm;
 #pragma unroll
@@ -428,6 +434,13 @@ __global__ __launch_bounds__(256) void k_unpack_bits(Geom g, const u64 *bits, ui
         const int p = y * g.Wp + x;
         out[i] = ((bits[p >> 6] >> (p & 63)) & 1ull) ? 255 : 0;
     }
+}
+
+void launch_pack_bits(const Geom &g, const uint8_t *in, u64 *bits, hipStream_t st)
+{
+    RangeParams rp;
+    rp.lo[0] = 1; rp.hi[0] = 255; rp.lo[1] = rp.lo[2] = 0; rp.hi[1] = rp.hi[2] = 255;
+    launch_inrange_bits(g, in, 1, rp, bits, st);     // nonzero == in [1,255]
 }
 
 void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st)

@@ -45,6 +45,7 @@ struct oatgpu_ctx {
     uint8_t *frames = nullptr;     // staging [n][H*W*3]
     uint8_t *aux_a = nullptr;      // [H*W*3]
     uint8_t *aux_b = nullptr;      // [H*W*3]
+    u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
     BlobBuffers bb[2]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
     const u64 *last_morph = nullptr;
     const u64 *last_fin = nullptr;
@@ -143,7 +144,7 @@ static MogParams mogparams_of(const oatgpu_config &k)
 static void free_all(oatgpu_ctx *c)
 {
     if (!c) return;
-    hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
+    hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
@@ -359,7 +360,7 @@ static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rat
 {
     MogLaunch a{};
     a.frames = frames; a.channels = c->cfg.channels; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = thr_buf(c, 0);
-    a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0;
+    a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0; a.roi_bits = c->roi;
     a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
     a.mp = mogparams_of(c->cfg);
     a.rp = range_of(c->cfg);
@@ -394,6 +395,31 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     HIPCHK(c, hipGetLastError());
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, c->aux_a, npx, hipMemcpyDeviceToHost, c->stream));
     if (bgr_out) HIPCHK(c, hipMemcpyAsync(bgr_out, c->aux_b, npx * ch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_set_roi_mask(oatgpu_ctx *c, int32_t s, const uint8_t *roi_mask)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
+    const Geom &g = c->g;
+    const size_t NW = g.Palloc >> 6, n = c->cfg.n_streams, npx = (size_t)g.H * g.W;
+    if (!c->roi) {
+        if (!roi_mask) return OATGPU_OK;                       // nothing to clear
+        HIPCHK(c, hipMalloc((void **)&c->roi, n * NW * 8));
+        HIPCHK(c, hipMemsetAsync(c->roi, 0xff, n * NW * 8, c->stream));   // other streams keep everything
+    }
+    if (!roi_mask) {
+        HIPCHK(c, hipMemsetAsync(c->roi + (size_t)s * NW, 0xff, NW * 8, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->aux_a, roi_mask, npx, hipMemcpyHostToDevice, c->stream));
+        launch_pack_bits(g, c->aux_a, c->roi + (size_t)s * NW, c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OATGPU_OK;
 }

@@ -100,6 +100,7 @@ struct MogLaunch {
     uint8_t *out_bgr;        // [n][H*W*3] masked frame or nullptr
     uint8_t *out_mask;       // [n][H*W] {0,127,255} or nullptr
     int out_base;            // out_bgr / out_mask are indexed by (stream - out_base)
+    const u64 *roi_bits;     // [n][Palloc/64] region-of-interest bits (framefilt mask fused in) or nullptr
     float alphaT, alpha1, prune;
     int fresh;               // 1: model is (re)initialised this frame -> no modes
     MogParams mp;
@@ -113,6 +114,8 @@ void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st
 void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
                          u64 *bits, hipStream_t st);
 void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st);
+// rows*cols bytes (nonzero = keep) -> bit mask of one stream
+void launch_pack_bits(const Geom &g, const uint8_t *in, u64 *bits, hipStream_t st);
 // model checkpoint: logical (OpenCV AoS) <-> device planes
 // state / nmodes point at ONE stream's model
 void launch_state_export(const Geom &g, float *state, uint8_t *nmodes, int nmix, int channels,

@@ -528,6 +528,37 @@ def test_batch_with_uneven_stream_histories_and_ring_depth_one(A):
         _same_state(hp.mog_state(s), orcs[s].state(), s)
 
 
+def test_roi_mask_fused_before_mog(A):
+    """`framefilt mask` -> `framefilt mog` -> ... (examples/two-color-test/track.sh:34-38): the ROI mask
+    (FrameMasker.cpp:71-75, frame.setTo(0, roi == 0)) fused into the per-pixel kernel, per stream."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols, n = 150, 200, 2
+    win = disc_hsv_window()
+    hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=0.02, erode=0, dilate=3, area=(3.0, 1e5), **win)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=0, dilate=3,
+                     min_area=3.0, max_area=1e5)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    roi = (((xx - 100) ** 2 + (yy - 75) ** 2) < 70 ** 2).astype(np.uint8) * 255     # circular arena
+    hp.set_roi_mask(roi, stream=1)                                                  # stream 0 stays unmasked
+    streams = [SyntheticStream(rows, cols, 20 + s, n_discs=1, radius=6) for s in range(n)]
+    orcs = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    for t in range(30):
+        frames = [st.frame(t, with_discs=t > 0) for st in streams]
+        got = hp.track(frames)
+        for s in range(n):
+            f = frames[s].copy()
+            if s == 1:
+                f[roi == 0] = 0
+            want, thr = O.chain_step(orcs[s], f, 0.02, p)
+            assert (hp.read_mask(1, s) == thr).all(), (t, s)
+            _same_detection(got[s], want, (t, s))
+    hp.set_roi_mask(None, stream=1)
+    frames = [st.frame(31) for st in streams]
+    got = hp.track(frames)
+    want, _ = O.chain_step(orcs[1], frames[1], 0.02, p)
+    _same_detection(got[1], want)
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135
