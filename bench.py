@@ -48,12 +48,13 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_hotpath(wl, device, ring_depth):
+def make_hotpath(wl, device, ring_depth, dense=False):
     import oat_amd
     from oat_amd.synth import disc_hsv_window
+    win = dict(h_thresh=(0, 256), s_thresh=(0, 256), v_thresh=(255, 256)) if dense else disc_hsv_window()
     return oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=wl["streams"], adaptation_coeff=ALPHA,
                            erode=wl["erode"], dilate=wl["dilate"], area=AREA, device=device,
-                           ring_depth=ring_depth, **disc_hsv_window())
+                           ring_depth=ring_depth, **win)
 
 
 def oracle_params(wl):
@@ -103,6 +104,21 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
     return dict(value=n / el, unit="frames/s", cores=ncores, kind="port",
                 sample=f"{n} frames of one {wl['cols']}x{wl['rows']} stream, {el:.1f} s, oracle chain "
                        f"(MOG2, HSV, inRange, morphology rows over {ncores} threads; contour following 1 thread)")
+
+
+def make_pool_dense(rows, cols, ns, nframes, rank, dev):
+    """Worst case for the model traffic: every pixel jumps among six well separated colours, so all
+    five mixture modes stay live and every plane is read and written every frame (205 B/px real)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xD0 + rank)
+    table = torch.tensor([[20, 30, 40], [90, 200, 60], [200, 60, 120], [240, 240, 230], [40, 130, 220], [140, 20, 150]],
+                         device=dev, dtype=torch.int16)
+    pool = []
+    for t in range(nframes):
+        idx = torch.randint(0, 6, (ns, rows, cols), device=dev, generator=g)
+        f = table[idx] + torch.randint(-5, 6, (ns, rows, cols, 3), device=dev, dtype=torch.int16, generator=g)
+        pool.append(f.clamp_(0, 255).to(torch.uint8).contiguous())
+    return pool
 
 
 def make_pool_device(rows, cols, ns, nframes, rank, dev):
@@ -159,6 +175,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dense-model", action="store_true",
+                    help="diagnostic: input that keeps all 5 mixture modes live on every pixel (K1 moves the full "
+                         "205 B/px) and a threshold window nothing passes; not a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -190,16 +209,16 @@ def main():
     # ids rank*ns ..): gradient + fresh +-6 noise per frame, every 64th pixel flickering, two
     # saturated discs per stream on Lissajous paths.  The pool is long enough that
     # a disc revisits a pixel too rarely to be learnt as background.
-    pool = make_pool_device(rows, cols, ns, args.pool, rank, dev)
+    pool = (make_pool_dense if args.dense_model else make_pool_device)(rows, cols, ns, args.pool, rank, dev)
     torch.cuda.synchronize()
     pool_host = [p[0:1].cpu().numpy() for p in pool[:8]]     # stream 0, for the parity gate / CPU baseline
 
     parity = "skipped"
-    if rank == 0 and not args.no_parity:
+    if rank == 0 and not args.no_parity and not args.dense_model:
         parity = parity_gate(wl, local_rank, [p[0] for p in pool_host[:4]])
         log("parity gate:", parity)
 
-    hp = make_hotpath(wl, local_rank, ring)
+    hp = make_hotpath(wl, local_rank, ring, dense=args.dense_model)
 
     def barrier():
         hp.synchronize()
@@ -308,6 +327,7 @@ def main():
         "positions_expected": total_streams * K,
         "parity": parity,
         "input": args.input,
+        "dense_model": bool(args.dense_model),
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, [p[0] for p in pool_host])

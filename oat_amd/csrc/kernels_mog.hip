@@ -203,11 +203,38 @@ __device__ __forceinline__ bool in_range3(int a, int b, int c, const RangeParams
 template <int N> struct VecOf;
 template <> struct VecOf<4> { typedef float4 F; typedef uchar4 B; };
 template <> struct VecOf<2> { typedef float2 F; typedef uchar2 B; };
+template <> struct VecOf<1> { typedef float F; typedef unsigned char B; };
 typedef VecOf<kPX>::F vecf;
+typedef float nvecf __attribute__((ext_vector_type(kPX)));   // native vector for the nontemporal builtins
+
+// Model plane access.  OATGPU_NT=1 marks the streamed planes nontemporal (A/B option).
+#ifndef OATGPU_NT
+#define OATGPU_NT 0
+#endif
+__device__ __forceinline__ void ld_plane(float *dst, const float *src)
+{
+#if OATGPU_NT
+    *(nvecf *)dst = __builtin_nontemporal_load((const nvecf *)src);
+#else
+    *(vecf *)dst = *(const vecf *)src;
+#endif
+}
+__device__ __forceinline__ void st_plane(float *dst, const float *src)
+{
+#if OATGPU_NT
+    __builtin_nontemporal_store(*(const nvecf *)src, (nvecf *)dst);
+#else
+    *(vecf *)dst = *(const vecf *)src;
+#endif
+}
 typedef VecOf<kPX>::B vecb;
 
+// OATGPU_WAVES: minimum waves per SIMD the register allocator must leave room for (A/B knob).
+#ifndef OATGPU_WAVES
+#define OATGPU_WAVES 1
+#endif
 template <int CH>
-__global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     __shared__ int sdiv[256];
     __shared__ int hdiv[256];
@@ -241,10 +268,10 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
         const uint8_t *nb = (const uint8_t *)&n4;
 #pragma unroll
         for (int j = 0; j < kPX; ++j) nmodes[j] = nb[j];
-        *(vecf *)W[0] = *(const vecf *)(st);
-        *(vecf *)V[0] = *(const vecf *)(st + (size_t)5 * PS);
+        ld_plane(W[0], st);
+        ld_plane(V[0], st + (size_t)5 * PS);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) *(vecf *)M[0][c] = *(const vecf *)(st + (size_t)(10 + c) * PS);
+        for (int c = 0; c < CH; ++c) ld_plane(M[0][c], st + (size_t)(10 + c) * PS);
         if (CH == 1) {
 #pragma unroll
             for (int j = 0; j < kPX; ++j) { M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
@@ -259,11 +286,11 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
 #pragma unroll
     for (int k = 1; k < kMaxMix; ++k) {
         if (k < nmax_old) {
-            *(vecf *)W[k] = *(const vecf *)(st + (size_t)k * PS);
-            *(vecf *)V[k] = *(const vecf *)(st + (size_t)(5 + k) * PS);
+            ld_plane(W[k], st + (size_t)k * PS);
+            ld_plane(V[k], st + (size_t)(5 + k) * PS);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-                *(vecf *)M[k][c] = *(const vecf *)(st + (size_t)(10 + 3 * k + c) * PS);
+                ld_plane(M[k][c], st + (size_t)(10 + 3 * k + c) * PS);
             if (CH == 1) {
 #pragma unroll
                 for (int j = 0; j < kPX; ++j) { M[k][1][j] = 0.f; M[k][2][j] = 0.f; }
@@ -346,12 +373,12 @@ __global__ __launch_bounds__(256) void k_mog_fused(Geom g, MogLaunch a, int firs
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
         if (wchg && k < nlive)
-            *(vecf *)(st + (size_t)k * PS) = *(const vecf *)W[k];
+            st_plane(st + (size_t)k * PS, W[k]);
         if ((dvm >> k) & 1u) {
-            *(vecf *)(st + (size_t)(5 + k) * PS) = *(const vecf *)V[k];
+            st_plane(st + (size_t)(5 + k) * PS, V[k]);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-                *(vecf *)(st + (size_t)(10 + 3 * k + c) * PS) = *(const vecf *)M[k][c];
+                st_plane(st + (size_t)(10 + 3 * k + c) * PS, M[k][c]);
         }
     }
     if (nchg) {

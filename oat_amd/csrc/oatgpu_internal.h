@@ -38,9 +38,13 @@ struct Geom {
 constexpr int kMogPlanes = 25;
 constexpr int kMaxMix = 5;
 #ifndef OATGPU_PX
-#define OATGPU_PX 4
+#define OATGPU_PX 1
 #endif
-constexpr int kPX = OATGPU_PX;            // pixels per lane of the MOG kernel (2 or 4)
+// Pixels per lane of the MOG kernel (1, 2 or 4).  Measured on MI355X at 4K: 4 px/lane (16-byte
+// loads, 165 VGPRs, 3 waves/SIMD) 138-145 us; 2 px/lane (108 VGPRs, 4 waves) 144 us; 1 px/lane (62 VGPRs,
+// 8 waves/SIMD, 4-byte loads) 113-123 us -- the kernel is latency-bound on its dependent load phases, so
+// occupancy beats load width.
+constexpr int kPX = OATGPU_PX;
 constexpr int kWavePx = 64 * kPX;         // pixels one wavefront owns
 
 __host__ __device__ inline int mog_slot(int p)
