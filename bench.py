@@ -89,7 +89,8 @@ def parity_gate(wl, device, frames_seq):
 def cpu_baseline(wl, frames_seq, budget_s=12.0):
     """The oracle (a port of the reference's CPU chain) timed on this host, bounded sample."""
     import oracle_lib as O
-    ncores = os.cpu_count() or 1
+    # the port spawns its row workers per stage (no pool): beyond ~32 threads creation cost eats the gain
+    ncores = min(os.cpu_count() or 1, 32)
     orc = O.Mog2(wl["rows"], wl["cols"], 3)
     p = oracle_params(wl)
     O.chain_step(orc, frames_seq[0], ALPHA, p, nthreads=ncores)      # frame 1 (model init), untimed

@@ -99,8 +99,8 @@ typedef struct oatgpu_profile {
     double morph_ms;           /* erode + dilate                              */
     double blob_ms;            /* labelling + contour sums + selection        */
     double total_ms;           /* first event to last event of each step      */
-    double event_pair_ms;      /* calibration: elapsed time of an EMPTY event pair on the
-                                  same HIP stream (what each *_ms above contains per step
+    double event_pair_ms;      /* calibration: elapsed time of an event pair around an EMPTY
+                                  kernel on the same HIP stream (what mog_ms contains per step
                                   besides kernel execution); measured at profile_enable */
 } oatgpu_profile;
 

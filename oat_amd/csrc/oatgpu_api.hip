@@ -758,7 +758,8 @@ extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
     if (!c) return OATGPU_E_INVALID;
     if (!on) prof_fold(c);
     if (on && !c->prof) {
-        // calibrate: what an event pair with NOTHING between it measures on stream A
+        // calibrate: what an event pair measures on stream A around a launch that does nothing
+        // (event processing + dispatch latency; the empty wave itself runs ~1 us)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipEvent_t e0, e1;
         HIPCHK(c, hipEventCreate(&e0));
@@ -766,6 +767,7 @@ extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
         float best = 1e30f;
         for (int i = 0; i < 16; ++i) {
             HIPCHK(c, hipEventRecord(e0, c->stream));
+            launch_nop(c->stream);
             HIPCHK(c, hipEventRecord(e1, c->stream));
             HIPCHK(c, hipEventSynchronize(e1));
             float ms = 0;
