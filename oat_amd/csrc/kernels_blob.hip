@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     int *carry = b.carry + (size_t)s * g.H * g.words + (size_t)y * g.words;
     int *parent = b.parent + (size_t)s * g.Palloc;
 
-    if (y == 0 && lane == 0) b.best[s] = 0ull;
+    if (y == 0 && lane == 0) b.nroots[s] = 0u;
 
     const bool frame_row = (y == 0) || (y == g.H - 1);
     const int lastx = g.W - 1;
@@ -317,198 +317,196 @@ __global__ __launch_bounds__(256) void k_merge(Geom g, BlobBuffers b, int first_
     }
 }
 
-// One thread = one word: every run head points straight at its root.
-__global__ __launch_bounds__(256) void k_flatten(Geom g, BlobBuffers b, int first_stream)
+// read-only walk to the root (after the merge kernel has completed: plain loads)
+__device__ __forceinline__ int uf_root(const int *parent, int i)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.H * g.words) return;
-    const int s = first_stream + blockIdx.y;
-    const int y = t / g.words, w = t - y * g.words;
-    u64 T = b.trans[(size_t)s * (g.Palloc >> 6) + t];
-    int *parent = b.parent + (size_t)s * g.Palloc;
-    while (T) {
-        const int i = lsb64(T);
-        T &= T - 1;
-        const int h = y * g.Wp + w * 64 + i;
-        const int r = uf_find(parent, h);
-        if (r != h) __hip_atomic_store(parent + h, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    int p = parent[i];
+    while (p != i) { i = p; p = parent[i]; }
+    return i;
 }
 
-// One thread = one word of an interior row: Green sums over the directed edges
-// of foreground pixels that face OUTSIDE background (root 0).
-__global__ __launch_bounds__(256) void k_green(Geom g, BlobBuffers b, int first_stream)
+// K5: contour sums + selection in ONE kernel.
+// Phase 1, one thread = one word of an interior row:
+//   * every foreground run head that is a root announces itself in the stream's root list;
+//   * Green sums over the directed edges of foreground pixels that face OUTSIDE background
+//     (root 0), accumulated per root with int64 atomics.  Roots are found by walking parent[]
+//     (no flatten pass); consecutive border pixels of one edge look at the same runs, so the last
+//     (run head -> root) pair per lookup class is memoised and a straight edge costs one walk.
+// Phase 2, the last workgroup of the stream to arrive (arrival counter; everything it reads that
+// this kernel wrote -- root list, sums -- is written and read with agent-scope atomics, each wave
+// drains vmcnt before arriving): every root offers (|a00| << 32 | first pixel); the maximum is
+// the largest area with ties going to the later first pixel -- the reference walks its reversed
+// contour list with a strict '>' -- and becomes the stream's result record in host-mapped memory.
+__global__ __launch_bounds__(256) void k_green_select(Geom g, BlobBuffers b, double min_area, double max_area,
+                                                      ResultRec *results, int first_stream)
 {
+    __shared__ int is_last;
+    __shared__ unsigned long long red[256];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (g.H - 2) * g.words) return;
     const int s = first_stream + blockIdx.y;
-    const int y = 1 + t / g.words, w = t % g.words;
     const size_t soff = (size_t)s * (g.Palloc >> 6);
     const u64 *fin = b.fin + soff;
     const u64 *trans = b.trans + soff;
     const int *carry = b.carry + (size_t)s * g.H * g.words;
     const int *parent = b.parent + (size_t)s * g.Palloc;
     long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+    int *roots = b.roots + (size_t)s * (g.Palloc >> 1);
 
-    const size_t rc = (size_t)y * g.words, ru = rc - g.words, rd = rc + g.words;
-    const u64 cur = fin[rc + w];
-    if (cur == 0ull) return;
-    const bool hp = w > 0, hn = w + 1 < g.words;
-    const u64 U = fin[ru + w], D = fin[rd + w];
-    const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
-    const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
-    const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
-    const u64 L = (cur << 1) | (curP >> 63), R = (cur >> 1) | (curN << 63);
-    const u64 UL = (U << 1) | (upP >> 63), UR = (U >> 1) | (upN << 63);
-    const u64 DL = (D << 1) | (dnP >> 63), DR = (D >> 1) | (dnN << 63);
+    u64 cur = 0ull;
+    int y = 0, w = 0;
+    if (t < (g.H - 2) * g.words) {
+        y = 1 + t / g.words; w = t % g.words;
+        cur = fin[(size_t)y * g.words + w];
+    }
+    if (cur != 0ull) {
+        const size_t rc = (size_t)y * g.words, ru = rc - g.words, rd = rc + g.words;
+        const u64 Tc = trans[rc + w];
+        // ---- roots announce themselves ----
+        u64 heads = Tc & cur;
+        while (heads) {
+            const int i = lsb64(heads);
+            heads &= heads - 1;
+            const int h = y * g.Wp + w * 64 + i;
+            if (parent[h] == h) {
+                const unsigned idx = __hip_atomic_fetch_add(&b.nroots[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(roots + idx, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- Green sums ----
+        const bool hp = w > 0, hn = w + 1 < g.words;
+        const u64 U = fin[ru + w], D = fin[rd + w];
+        const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
+        const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
+        const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
+        const u64 L = (cur << 1) | (curP >> 63), R = (cur >> 1) | (curN << 63);
+        const u64 UL = (U << 1) | (upP >> 63), UR = (U >> 1) | (upN << 63);
+        const u64 DL = (D << 1) | (dnP >> 63), DR = (D >> 1) | (dnN << 63);
 
-    u64 cand = cur & ~(L & R & U & D);
-    const u64 Tc = trans[rc + w], Tu = trans[ru + w], Td = trans[rd + w];
-    const int cc = carry[rc + w], cu = carry[ru + w], cd = carry[rd + w];
+        u64 cand = cur & ~(L & R & U & D);
+        const u64 Tu = trans[ru + w], Td = trans[rd + w];
+        const int cc = carry[rc + w], cu = carry[ru + w], cd = carry[rd + w];
 
-    // Consecutive border pixels of one edge look at the same runs: remember the last
-    // (run head -> root) pair per lookup class so a straight edge costs one parent[] load.
-    struct Memo { int head, root; };
-    Memo mo{-1, 0}, ml{-1, 0}, mb{-1, 0}, mr{-1, 0}, mt{-1, 0};
-    auto root_of = [&](Memo &m, int head) -> int {
-        if (head != m.head) { m.head = head; m.root = parent[head]; }
-        return m.root;
-    };
-
-    int label = -1;
-    long long s00 = 0, s10 = 0, s01 = 0;
-    while (cand) {
-        const int i = lsb64(cand);
-        cand &= cand - 1;
-        const int x = w * 64 + i;
-        const u64 bit = 1ull << i;
-        const int lab = root_of(mo, run_head_w(g, Tc, cc, y, w, i));
-        if (lab != label) {
+        struct Memo { int head, root; };
+        Memo mo{-1, 0}, ml{-1, 0}, mb{-1, 0}, mr{-1, 0}, mt{-1, 0};
+        auto root_of = [&](Memo &m, int head) -> int {
+            if (head != m.head) { m.head = head; m.root = uf_root(parent, head); }
+            return m.root;
+        };
+        auto flush = [&](int label, long long s00, long long s10, long long s01) {
             if (label >= 0 && (s00 | s10 | s01)) {
                 atomicAdd((unsigned long long *)&acc[(size_t)label * 3], (unsigned long long)s00);
                 atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 1], (unsigned long long)s10);
                 atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 2], (unsigned long long)s01);
             }
-            label = lab; s00 = s10 = s01 = 0;
-        }
-        // side: neighbour bg pixel, then B (diagonal, first) and A (straight, second)
-        int qx, qy;
-        bool e;
-#define OAT_EDGE()                                                                    \
-        if (e) {                                                                      \
-            const int d = x * qy - qx * y;                                            \
-            s00 += d; s10 += (long long)d * (x + qx); s01 += (long long)d * (y + qy); \
-        }
-        if (!(L & bit)) {                                                             // left
-            const int h = i > 0 ? run_head_w(g, Tc, cc, y, w, i - 1) : run_head(g, trans, carry, y, x - 1);
-            if (root_of(ml, h) == 0) {
-                e = true;
-                if (DL & bit) { qx = x - 1; qy = y + 1; } else if (D & bit) { qx = x; qy = y + 1; } else e = false;
-                OAT_EDGE()
-            }
-        }
-        if (!(D & bit) && root_of(mb, run_head_w(g, Td, cd, y + 1, w, i)) == 0) {    // bottom
-            e = true;
-            if (DR & bit) { qx = x + 1; qy = y + 1; } else if (R & bit) { qx = x + 1; qy = y; } else e = false;
-            OAT_EDGE()
-        }
-        if (!(R & bit)) {                                                             // right
-            const int h = i < 63 ? run_head_w(g, Tc, cc, y, w, i + 1) : run_head(g, trans, carry, y, x + 1);
-            if (root_of(mr, h) == 0) {
-                e = true;
-                if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
-                OAT_EDGE()
-            }
-        }
-        if (!(U & bit) && root_of(mt, run_head_w(g, Tu, cu, y - 1, w, i)) == 0) {    // top
-            e = true;
-            if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
-            OAT_EDGE()
-        }
-#undef OAT_EDGE
-    }
-    if (label >= 0 && (s00 | s10 | s01)) {
-        atomicAdd((unsigned long long *)&acc[(size_t)label * 3], (unsigned long long)s00);
-        atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 1], (unsigned long long)s10);
-        atomicAdd((unsigned long long *)&acc[(size_t)label * 3 + 2], (unsigned long long)s01);
-    }
-}
+        };
 
-// One thread = one word: every foreground root offers (|a00|, first pixel) as a
-// packed key; atomicMax keeps the largest area, ties -> the later first pixel
-// (the reference walks its reversed list with a strict '>').  The last
-// workgroup of a stream to finish (arrival counter, agent-scope release /
-// acquire) turns the winning key into the stream's result record, written
-// straight into host-mapped memory.
-__global__ __launch_bounds__(256) void k_select(Geom g, BlobBuffers b, double min_area, double max_area,
-                                                ResultRec *results, int first_stream)
-{
-    __shared__ int is_last;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = first_stream + blockIdx.y;
-    if (t < g.H * g.words) {
-        const int y = t / g.words, w = t - y * g.words;
-        const size_t soff = (size_t)s * (g.Palloc >> 6);
-        u64 heads = b.trans[soff + t] & b.fin[soff + t];
-        const int *parent = b.parent + (size_t)s * g.Palloc;
-        const long long *acc = b.acc + (size_t)s * g.Palloc * 3;
-        while (heads) {
-            const int i = lsb64(heads);
-            heads &= heads - 1;
-            const int h = y * g.Wp + w * 64 + i;
-            if (parent[h] != h) continue;
-            const long long a00 = acc[(size_t)h * 3];
-            if (a00 == 0) continue;
-            const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
-            const double area = (double)mag * 0.5;        // m00 = a00 * (+-0.5), exact
-            if (area >= min_area && area < max_area)
-                atomicMax((unsigned long long *)&b.best[s], (mag << 32) | (u64)(unsigned)h);
+        int label = -1;
+        long long s00 = 0, s10 = 0, s01 = 0;
+        while (cand) {
+            const int i = lsb64(cand);
+            cand &= cand - 1;
+            const int x = w * 64 + i;
+            const u64 bit = 1ull << i;
+            const int lab = root_of(mo, run_head_w(g, Tc, cc, y, w, i));
+            if (lab != label) { flush(label, s00, s10, s01); label = lab; s00 = s10 = s01 = 0; }
+            // side: neighbour bg pixel, then B (diagonal, first) and A (straight, second)
+            int qx, qy;
+            bool e;
+#define OAT_EDGE()                                                                        \
+            if (e) {                                                                      \
+                const int d = x * qy - qx * y;                                            \
+                s00 += d; s10 += (long long)d * (x + qx); s01 += (long long)d * (y + qy); \
+            }
+            if (!(L & bit)) {                                                             // left
+                const int h = i > 0 ? run_head_w(g, Tc, cc, y, w, i - 1) : run_head(g, trans, carry, y, x - 1);
+                if (root_of(ml, h) == 0) {
+                    e = true;
+                    if (DL & bit) { qx = x - 1; qy = y + 1; } else if (D & bit) { qx = x; qy = y + 1; } else e = false;
+                    OAT_EDGE()
+                }
+            }
+            if (!(D & bit) && root_of(mb, run_head_w(g, Td, cd, y + 1, w, i)) == 0) {    // bottom
+                e = true;
+                if (DR & bit) { qx = x + 1; qy = y + 1; } else if (R & bit) { qx = x + 1; qy = y; } else e = false;
+                OAT_EDGE()
+            }
+            if (!(R & bit)) {                                                             // right
+                const int h = i < 63 ? run_head_w(g, Tc, cc, y, w, i + 1) : run_head(g, trans, carry, y, x + 1);
+                if (root_of(mr, h) == 0) {
+                    e = true;
+                    if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
+                    OAT_EDGE()
+                }
+            }
+            if (!(U & bit) && root_of(mt, run_head_w(g, Tu, cu, y - 1, w, i)) == 0) {    // top
+                e = true;
+                if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
+                OAT_EDGE()
+            }
+#undef OAT_EDGE
         }
+        flush(label, s00, s10, s01);
     }
-    // Hand-off to the last-arriving workgroup.  Everything it reads that THIS kernel wrote is
-    // written and read with agent-scope atomics (best[] via atomicMax / atomic load, the arrival
-    // counter): every wave drains its atomics (vmcnt) before the workgroup arrives, so no
-    // release/acquire fence -- and no L2 write-back per workgroup -- is needed.  acc[] and
-    // parent[] come from earlier kernels.
+
+    // ---- arrival; the last workgroup of this stream selects ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(&b.done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (prev == gridDim.x - 1) ? 1 : 0;
-        if (is_last) {
-            const u64 key = __hip_atomic_load((unsigned long long *)&b.best[s], __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-            ResultRec r;
-            r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
-            if (key) {
-                const int h = (int)(key & 0xffffffffull);
-                const long long *acc = b.acc + ((size_t)s * g.Palloc + h) * 3;
-                r.a00 = acc[0]; r.a10 = acc[1]; r.a01 = acc[2];
-                const int y = h / g.Wp, x = h - y * g.Wp;
-                r.first_pixel = y * g.W + x;
-                r.valid = 1;
-            }
-            results[s] = r;
-            __hip_atomic_store(&b.done[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+
+    const unsigned nr = __hip_atomic_load(&b.nroots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long best = 0ull;
+    for (unsigned i = threadIdx.x; i < nr; i += blockDim.x) {
+        const int h = __hip_atomic_load(roots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long a00 = __hip_atomic_load(&acc[(size_t)h * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a00 == 0) continue;
+        const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
+        const double area = (double)mag * 0.5;            // m00 = a00 * (+-0.5), exact
+        if (area >= min_area && area < max_area) {
+            const unsigned long long key = (mag << 32) | (u64)(unsigned)h;
+            best = key > best ? key : best;
         }
+    }
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st && red[threadIdx.x + st] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const u64 key = red[0];
+        ResultRec r;
+        r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
+        if (key) {
+            const int h = (int)(key & 0xffffffffull);
+            r.a00 = __hip_atomic_load(&acc[(size_t)h * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.a10 = __hip_atomic_load(&acc[(size_t)h * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.a01 = __hip_atomic_load(&acc[(size_t)h * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int yy = h / g.Wp, xx = h - yy * g.Wp;
+            r.first_pixel = yy * g.W + xx;
+            r.valid = 1;
+        }
+        results[s] = r;
+        __hip_atomic_store(&b.done[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st)
 {
-    const int nw = g.H * g.words;
     hipLaunchKernelGGL(k_rowscan, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, dil_k, b,
                        first_stream);
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);
-    hipLaunchKernelGGL(k_flatten, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, first_stream);
-    if (g.H > 2)
-        hipLaunchKernelGGL(k_green, dim3(((g.H - 2) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
-                           first_stream);
-    hipLaunchKernelGGL(k_select, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, min_area, max_area,
-                       results, first_stream);
+    // (grid of at least one workgroup even for H <= 2: the last-arriver logic writes the result)
+    const int nw = g.H > 2 ? (g.H - 2) * g.words : 1;
+    hipLaunchKernelGGL(k_green_select, dim3((nw + 255) / 256, n_streams), dim3(256), 0, st, g, b, min_area,
+                       max_area, results, first_stream);
 }
 
 }  // namespace oatgpu

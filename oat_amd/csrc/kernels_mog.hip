@@ -489,8 +489,8 @@ __device__ __forceinline__ float *state_elem(const Geom &g, float *sbase, int pl
 }
 __device__ __forceinline__ uint8_t *count_elem(const Geom &g, float *sbase, uint8_t *nmodes, int p)
 {
-    const int base = p - (p % kWavePx);
 #if OATGPU_TILED
+    const int base = p - (p % kWavePx);
     (void)nmodes;
     return (uint8_t *)sbase + mog_count_off(g.Palloc, base) + (mog_slot(p) - base);
 #else

@@ -148,7 +148,8 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bb[0].thr);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
-        hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.best); hipFree(b.done);
+        hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
+        hipFree(b.roots); hipFree(b.nroots);
     }
     if (c->res_host) hipHostFree(c->res_host);
     for (int q = 0; q < 2; ++q) {
@@ -239,8 +240,9 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         A((void **)&b.carry, n * (size_t)g.H * g.words * sizeof(int));
         A((void **)&b.parent, n * PA * sizeof(int));
         A((void **)&b.acc, n * PA * 3 * sizeof(long long));
-        A((void **)&b.best, n * 8);
         A((void **)&b.done, n * sizeof(unsigned));
+        A((void **)&b.roots, n * (PA / 2) * sizeof(int));
+        A((void **)&b.nroots, n * sizeof(unsigned));
     }
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
@@ -257,8 +259,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb[0].thr, 0, 4 * n * NW * 8, c->stream) != hipSuccess) ok = false;
     for (auto &b : c->bb) {
-        if (ok && hipMemsetAsync(b.best, 0, n * 8, c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+        if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {

@@ -139,8 +139,9 @@ struct BlobBuffers {
     int *carry;      // [n][H*words]   start x of the run entering each word
     int *parent;     // [n][Palloc]    union-find over run heads (sparse)
     long long *acc;  // [n][Palloc][3] Green sums per root (sparse)
-    u64 *best;       // [n]            packed selection key
-    unsigned *done;  // [n]            workgroup arrival counter of k_select
+    unsigned *done;  // [n]            workgroup arrival counter of k_green_select
+    int *roots;      // [n][Palloc/2]  foreground roots of the current frame
+    unsigned *nroots;// [n]
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
