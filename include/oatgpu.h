@@ -79,6 +79,10 @@ typedef struct oatgpu_config {
     int32_t erode;             /* -e, 0 = off                                 */
     int32_t dilate;            /* -d, 0 = off                                 */
     double min_area, max_area; /* -a [min,max)                                */
+
+    /* --- posidet diff (DifferenceDetector.h:63-76) --- */
+    int32_t diff_threshold;    /* -d, default 10                              */
+    int32_t blur;              /* -b, default 2; 0 = off; <= 22 supported     */
 } oatgpu_config;
 
 /* What posidet writes into oat::Position2D (src/positiondetector/DetectorFunc.cpp:46,58-60)
@@ -155,6 +159,13 @@ int oatgpu_detect_hsv(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *hsv_in,
  * uses h_lo/h_hi as -T [min,max]. */
 int oatgpu_detect_thresh(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *grey_in,
                          oatgpu_position *out);
+
+/* DifferenceDetector::detectPosition (DifferenceDetector.cpp:98-173): grey_in rows*cols.  Stateful
+ * per camera stream (the previous frame); the first frame of a stream is analysed as is, like the
+ * reference.  For blur <= 22 a box blur of a {0,255} image is non-zero exactly where the k x k
+ * dilation is (away from the outermost ring, which findContours zeroes), so the blur runs as a
+ * bit-mask dilation. */
+int oatgpu_detect_diff(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *grey_in, oatgpu_position *out);
 
 /* ---- fused hot path: mog + setTo + BGR2HSV + inRange + erode + dilate + blob ---- */
 

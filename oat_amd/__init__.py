@@ -9,8 +9,8 @@ by the tests and the benchmark; there is no CPU fallback -- importing
 """
 from .ffi import OatGpuError, lib_path  # noqa: F401
 from .components import (  # noqa: F401
-    BackgroundSubtractorMOG, ColorConvert, HSVDetector, SimpleThreshold, HotPath, Position2D,
+    BackgroundSubtractorMOG, ColorConvert, HSVDetector, SimpleThreshold, DifferenceDetector, HotPath, Position2D,
 )
 
-__all__ = ["BackgroundSubtractorMOG", "ColorConvert", "HSVDetector", "SimpleThreshold", "HotPath",
+__all__ = ["BackgroundSubtractorMOG", "ColorConvert", "HSVDetector", "SimpleThreshold", "DifferenceDetector", "HotPath",
            "Position2D", "OatGpuError", "lib_path"]

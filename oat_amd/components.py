@@ -185,6 +185,20 @@ class SimpleThreshold(_Detector):
         return _merge(position, p)
 
 
+class DifferenceDetector(_Detector):
+    """posidet diff.  Options follow DifferenceDetector.cpp:47-64 (-d diff-threshold, -b blur, -a area)."""
+
+    def __init__(self, rows, cols, diff_threshold=10, blur=2, area=(0.0, DBL_MAX), **kw):
+        super().__init__(rows, cols, diff_threshold=diff_threshold, blur=blur, erode=0, dilate=0,
+                         min_area=area[0], max_area=area[1], **kw)
+
+    def detectPosition(self, frame, position=None, stream=0):
+        f = _frame(frame, (self.rows, self.cols))
+        p = ffi.Position()
+        self._chk(self.lib.oatgpu_detect_diff(self.ctx, stream, ffi.u8(f), C.byref(p)))
+        return _merge(position, p)
+
+
 def _merge(position, p):
     """siftContours only writes x/y when a blob is found (DetectorFunc.cpp:46,58-60)."""
     new = Position2D.from_c(p)

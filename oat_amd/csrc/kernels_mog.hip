@@ -456,6 +456,36 @@ void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, cons
     hipLaunchKernelGGL(k_inrange_bits, dim3((nwords + 3) / 4), dim3(256), 0, st, g, frame, channels, rp, bits);
 }
 
+// posidet diff: cv::absdiff + cv::threshold(THRESH_BINARY) of a GREY frame against the previous one
+// (DifferenceDetector.cpp:156-161), one wave = one mask word; also refreshes the previous frame.
+__global__ __launch_bounds__(256) void k_absdiff_bits(Geom g, const uint8_t *frame, uint8_t *last, int thr,
+                                                      int have_last, u64 *bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= (g.Palloc >> 6)) return;
+    const int p = word * 64 + lane;
+    const int y = p / g.Wp, x = p - y * g.Wp;
+    const bool valid = p < g.P && x < g.W;
+    bool on = false;
+    if (valid) {
+        const size_t i = (size_t)y * g.W + x;
+        const int v = frame[i];
+        if (have_last) { const int l = last[i]; on = (v > l ? v - l : l - v) > thr; }
+        else on = v != 0;                       // first frame: threshold_frame_ = frame.clone()
+        last[i] = (uint8_t)v;
+    }
+    const u64 w = __ballot(on);
+    if (lane == 0) bits[word] = w;
+}
+
+void launch_absdiff_bits(const Geom &g, const uint8_t *frame, uint8_t *last, int thr, int have_last, u64 *bits,
+                         hipStream_t st)
+{
+    const int nwords = g.Palloc >> 6;
+    hipLaunchKernelGGL(k_absdiff_bits, dim3((nwords + 3) / 4), dim3(256), 0, st, g, frame, last, thr, have_last, bits);
+}
+
 __global__ __launch_bounds__(256) void k_unpack_bits(Geom g, const u64 *bits, uint8_t *out)
 {
     const size_t npx = (size_t)g.H * g.W;

@@ -45,6 +45,8 @@ struct oatgpu_ctx {
     uint8_t *frames = nullptr;     // staging [n][H*W*3]
     uint8_t *aux_a = nullptr;      // [H*W*3]
     uint8_t *aux_b = nullptr;      // [H*W*3]
+    uint8_t *diff_last = nullptr;  // [n][H*W] previous GREY frame of posidet diff, allocated on first use
+    std::vector<char> diff_have;   // per camera stream
     u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
     BlobBuffers bb[2]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
     const u64 *last_morph = nullptr;
@@ -100,6 +102,7 @@ extern "C" int oatgpu_default_config(oatgpu_config *c)
     // HSVDetector.h:77-94, HSVDetector.cpp:42-43
     c->h_lo = 0; c->h_hi = 256; c->s_lo = 0; c->s_hi = 256; c->v_lo = 0; c->v_hi = 256;
     c->erode = 0; c->dilate = 10; c->min_area = 0.0; c->max_area = DBL_MAX;
+    c->diff_threshold = 10; c->blur = 2;       // DifferenceDetector.h:74, DifferenceDetector.cpp:41
     return OATGPU_OK;
 }
 
@@ -112,6 +115,8 @@ static int check_detector(oatgpu_ctx *c, const oatgpu_config &k)
     if (k.erode < 0 || k.dilate < 0) return fail(c, OATGPU_E_INVALID, "erode/dilate must be >= 0");
     if (k.erode > 63 || k.dilate > 63)
         return fail(c, OATGPU_E_INVALID, "erode/dilate kernel sizes above 63 are not supported");
+    if (k.blur < 0 || k.blur > 22)
+        return fail(c, OATGPU_E_INVALID, "blur must be in 0..22 (above that a box blur is no longer a dilation)");
     if (!(k.min_area < k.max_area))   // HSVDetector.cpp:135
         return fail(c, OATGPU_E_INVALID, "Max area should be larger than min area.");
     return OATGPU_OK;
@@ -144,7 +149,7 @@ static MogParams mogparams_of(const oatgpu_config &k)
 static void free_all(oatgpu_ctx *c)
 {
     if (!c) return;
-    hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
+    hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
@@ -205,6 +210,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     g.P = g.H * g.Wp; g.Palloc = (g.P + 1023) / 1024 * 1024; g.n_streams = cfg->n_streams;
     const size_t n = cfg->n_streams, npx = (size_t)g.H * g.W, PA = g.Palloc, NW = PA / 64;
     c->nframes.assign(n, 0);
+    c->diff_have.assign(n, 0);
 
     bool ok = true;
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
@@ -474,16 +480,18 @@ static void to_position(const ResultRec &r, oatgpu_position *o)
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
 // the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
 static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int n, int slot, hipStream_t st,
-                     hipEvent_t ev_mid)
+                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1)
 {
     const Geom &g = c->g;
     const u64 *src = thr;
-    if (c->cfg.erode > 1) {
-        launch_morph(g, src, bb.tmp, c->cfg.erode, true, s0, n, st);
+    if (erode_k < 0) erode_k = c->cfg.erode;
+    if (dilate_k < 0) dilate_k = c->cfg.dilate;
+    if (erode_k > 1) {
+        launch_morph(g, src, bb.tmp, erode_k, true, s0, n, st);
         src = bb.tmp;
     }
     if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, st));
-    const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+    const int dil = dilate_k > 1 ? dilate_k : 0;
     c->last_morph = dil ? bb.morph : src;
     c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
@@ -507,6 +515,32 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
     launch_inrange_bits(g, c->aux_a, channels, rp, thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
     const int slot = c->ring_slots;       // the extra slot
     rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
+    if (rc) return rc;
+    c->last_q = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_detect_diff(oatgpu_ctx *c, int32_t s, const uint8_t *grey_in, oatgpu_position *out)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!grey_in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
+    const Geom &g = c->g;
+    const size_t npx = (size_t)g.H * g.W;
+    if (!c->diff_last) HIPCHK(c, hipMalloc((void **)&c->diff_last, (size_t)c->cfg.n_streams * npx));
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, grey_in, npx, hipMemcpyHostToDevice, c->stream));
+    const int have = c->diff_have[s];
+    launch_absdiff_bits(g, c->aux_a, c->diff_last + (size_t)s * npx, c->cfg.diff_threshold, have,
+                        thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
+    c->diff_have[s] = 1;
+    const int slot = c->ring_slots;
+    // the first frame is analysed unblurred (DifferenceDetector.cpp:167-171); afterwards blur == dilation
+    rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr, 0, have ? c->cfg.blur : 0);
     if (rc) return rc;
     c->last_q = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));

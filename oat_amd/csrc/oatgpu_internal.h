@@ -118,6 +118,9 @@ void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st
 // 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.
 void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
                          u64 *bits, hipStream_t st);
+// posidet diff front end of ONE frame: bits = |frame - last| > thr (or frame != 0 when !have_last); last = frame
+void launch_absdiff_bits(const Geom &g, const uint8_t *frame, uint8_t *last, int thr, int have_last, u64 *bits,
+                         hipStream_t st);
 void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_t st);
 // rows*cols bytes (nonzero = keep) -> bit mask of one stream
 void launch_pack_bits(const Geom &g, const uint8_t *in, u64 *bits, hipStream_t st);

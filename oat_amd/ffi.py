@@ -27,6 +27,7 @@ class Config(C.Structure):
         ("h_lo", C.c_int32), ("h_hi", C.c_int32), ("s_lo", C.c_int32), ("s_hi", C.c_int32),
         ("v_lo", C.c_int32), ("v_hi", C.c_int32), ("erode", C.c_int32), ("dilate", C.c_int32),
         ("min_area", C.c_double), ("max_area", C.c_double),
+        ("diff_threshold", C.c_int32), ("blur", C.c_int32),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
+    "oatgpu_detect_diff": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_track_batch": (C.c_int, [_ctx, C.POINTER(_u8p), C.c_int32, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_batch_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_enqueue_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double]),

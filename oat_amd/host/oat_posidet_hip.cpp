@@ -1,6 +1,7 @@
 // oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]
 //   TYPE  hsv     replacement of `oat posidet hsv`    (src/positiondetector/HSVDetector.cpp)
 //         thresh  replacement of `oat posidet thresh` (src/positiondetector/SimpleThreshold.cpp)
+//         diff    replacement of `oat posidet diff`   (src/positiondetector/DifferenceDetector.cpp)
 // Same positional arguments and option names as src/positiondetector/main.cpp:85-271.
 #include "component.hpp"
 
@@ -8,13 +9,15 @@
 
 using namespace oat;
 
+enum class Kind { HSV, THRESH, DIFF };
+
 class GpuDetector : public PositionDetector {
 public:
-    GpuDetector(const std::string &src, const std::string &snk, bool hsv) : PositionDetector(src, snk), hsv_(hsv)
+    GpuDetector(const std::string &src, const std::string &snk, Kind kind) : PositionDetector(src, snk), kind_(kind)
     {
         oatgpu_default_config(&cfg_);
-        if (hsv) { required_color_ = PIX_HSV; cfg_.erode = 0; cfg_.dilate = 10; }       // HSVDetector.cpp:42-46
-        else { required_color_ = PIX_GREY; cfg_.erode = 0; cfg_.dilate = 0; }           // SimpleThreshold.cpp:42-46
+        if (kind == Kind::HSV) { required_color_ = PIX_HSV; cfg_.erode = 0; cfg_.dilate = 10; }   // HSVDetector.cpp:42-46
+        else { required_color_ = PIX_GREY; cfg_.erode = 0; cfg_.dilate = 0; }   // SimpleThreshold.cpp:42-46, DifferenceDetector.cpp:41-44
     }
     oatgpu_config cfg_;
 
@@ -28,17 +31,20 @@ protected:
     void detectPosition(Frame &frame, Position2D &position) override
     {
         oatgpu_position r;
-        gpu_.check(hsv_ ? oatgpu_detect_hsv(gpu_.ctx, 0, frame.data(), &r) : oatgpu_detect_thresh(gpu_.ctx, 0, frame.data(), &r));
+        gpu_.check(kind_ == Kind::HSV ? oatgpu_detect_hsv(gpu_.ctx, 0, frame.data(), &r)
+                   : kind_ == Kind::THRESH ? oatgpu_detect_thresh(gpu_.ctx, 0, frame.data(), &r)
+                                           : oatgpu_detect_diff(gpu_.ctx, 0, frame.data(), &r));
         position.position_valid = r.valid != 0;                   // DetectorFunc.cpp:46,58-60
         if (r.valid) { position.position.x = r.x; position.position.y = r.y; }
     }
-    bool hsv_;
+    Kind kind_;
     GpuCtx gpu_;
 };
 
 static void usage()
 {
-    std::cout << "Usage: oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]\nTYPE\n  hsv | thresh\n"
+    std::cout << "Usage: oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]\nTYPE\n  hsv | thresh | diff\n"
+                 "diff:   -d diff-threshold (default 10)  -b blur (default 2, <= 22)  -a [min,max] area\n"
                  "hsv:    -H/-S/-V [min,max] in [0,256]  -e erode  -d dilate (default 10)  -a [min,max] area\n"
                  "thresh: -T [min,max]  -e erode  -d dilate  -a [min,max] area\n";
 }
@@ -46,14 +52,18 @@ static void usage()
 int main(int argc, char **argv)
 {
     try {
+        // -d is "dilate" for hsv/thresh and "diff-threshold" for diff (DifferenceDetector.cpp:49-50)
+        const bool is_diff = argc > 1 && std::string(argv[1]) == "diff";
         Options o = Options::parse(argc, argv,
-            {{"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"T", "thresh"}, {"e", "erode"}, {"d", "dilate"},
-             {"a", "area"}, {"t", "tune"}, {"h", "help"}}, {"help", "tune"});
+            {{"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"T", "thresh"}, {"e", "erode"},
+             {"d", is_diff ? "diff-threshold" : "dilate"}, {"b", "blur"}, {"a", "area"}, {"t", "tune"}, {"h", "help"}},
+            {"help", "tune"});
         if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
         const std::string type = o.positional[0];
-        if (type != "hsv" && type != "thresh") throw std::runtime_error("Selected TYPE is invalid.");
+        if (type != "hsv" && type != "thresh" && type != "diff") throw std::runtime_error("Selected TYPE is invalid.");
         if (o.has("tune")) throw std::runtime_error("--tune needs a GUI and is not available in the hip detector");
-        auto d = std::make_unique<GpuDetector>(o.positional[1], o.positional[2], type == "hsv");
+        auto d = std::make_unique<GpuDetector>(o.positional[1], o.positional[2],
+                                               type == "hsv" ? Kind::HSV : type == "thresh" ? Kind::THRESH : Kind::DIFF);
         double a, b;
         auto range = [](double x, double y, const char *what) {
             if (x < 0 || x > 256 || y < 0 || y > 256) throw std::runtime_error(std::string("Values of ") + what + " should be between 0 and 256.");
@@ -63,6 +73,8 @@ int main(int argc, char **argv)
             if (o.arr2("s-thresh", a, b)) { range(a, b, "s-thresh"); d->cfg_.s_lo = (int)a; d->cfg_.s_hi = (int)b; }
             if (o.arr2("v-thresh", a, b)) { range(a, b, "v-thresh"); d->cfg_.v_lo = (int)a; d->cfg_.v_hi = (int)b; }
         } else if (o.arr2("thresh", a, b)) { range(a, b, "thresh"); d->cfg_.h_lo = (int)a; d->cfg_.h_hi = (int)b; }
+        if (o.has("diff-threshold")) d->cfg_.diff_threshold = (int)o.num("diff-threshold", 10, 0, 1e6);
+        if (o.has("blur")) d->cfg_.blur = (int)o.num("blur", 2, 0, 1e6);
         if (o.has("erode")) d->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
         if (o.has("dilate")) d->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
         if (o.arr2("area", a, b)) {

@@ -362,6 +362,50 @@ void oat_sift_cracks(const uint8_t *thr, int rows, int cols, double min_area, do
     free(fg); free(outside); free(label); free(stack); free(a00); free(a10); free(a01);
 }
 
+/* ------------------------------------------------------ posidet diff -------- */
+
+struct oat_diff {
+    int rows, cols, thresh, blur, last_set;
+    double min_area, max_area;
+    uint8_t *last;
+};
+
+oat_diff *oat_diff_create(int rows, int cols, int diff_threshold, int blur, double min_area, double max_area)
+{
+    oat_diff *d = (oat_diff *)calloc(1, sizeof(*d));
+    d->rows = rows; d->cols = cols; d->thresh = diff_threshold; d->blur = blur;
+    d->min_area = min_area; d->max_area = max_area;
+    d->last = (uint8_t *)malloc((size_t)rows * cols);
+    return d;
+}
+
+void oat_diff_destroy(oat_diff *d)
+{
+    if (!d) return;
+    free(d->last); free(d);
+}
+
+/* DifferenceDetector::applyThreshold (DifferenceDetector.cpp:154-173) + siftContours (:109-113) */
+void oat_diff_detect(oat_diff *d, const uint8_t *grey, uint8_t *thr_out, oat_detection *out)
+{
+    size_t n = (size_t)d->rows * d->cols;
+    uint8_t *thr = (uint8_t *)malloc(n);
+    if (d->last_set) {
+        for (size_t i = 0; i < n; i++) {
+            int a = grey[i] > d->last[i] ? grey[i] - d->last[i] : d->last[i] - grey[i];   /* cv::absdiff */
+            thr[i] = a > d->thresh ? 255 : 0;                                               /* THRESH_BINARY */
+        }
+        if (d->blur > 0) oat_blur_box(thr, thr, d->rows, d->cols, d->blur);
+    } else {
+        memcpy(thr, grey, n);            /* first frame: threshold_frame_ = frame.clone() */
+        d->last_set = 1;
+    }
+    memcpy(d->last, grey, n);
+    if (thr_out) memcpy(thr_out, thr, n);
+    oat_sift_contours(thr, d->rows, d->cols, d->min_area, d->max_area, out);
+    free(thr);
+}
+
 /* ------------------------------------------------------- detector chains -- */
 
 void oat_hsv_default_params(oat_hsv_params *p)

@@ -142,6 +142,18 @@ void oat_sift_contours(uint8_t *thr, int rows, int cols, double min_area, double
 void oat_sift_cracks(const uint8_t *thr, int rows, int cols, double min_area, double max_area,
                      oat_detection *out);
 
+/* cv::blur(src, dst, Size(k,k)) on 8U: normalised box filter, anchor (k/2,k/2), BORDER_REFLECT_101,
+ * dst = cvRound(sum * (1.0 / (k*k)))  (DifferenceDetector.cpp:160-161).  src/dst may alias. */
+void oat_blur_box(const uint8_t *src, uint8_t *dst, int rows, int cols, int k);
+
+/* DifferenceDetector (posidet diff), DifferenceDetector.cpp:98-173: stateful (last frame). */
+typedef struct oat_diff oat_diff;
+oat_diff *oat_diff_create(int rows, int cols, int diff_threshold /*10*/, int blur /*2, 0 = off*/,
+                          double min_area, double max_area);
+void oat_diff_destroy(oat_diff *d);
+/* grey: rows*cols.  thr_out (may be NULL) receives threshold_frame_ before findContours destroys it. */
+void oat_diff_detect(oat_diff *d, const uint8_t *grey, uint8_t *thr_out, oat_detection *out);
+
 /* ----------------------------------------------------- detector chains ---- */
 
 typedef struct {

@@ -158,3 +158,38 @@ void oat_dilate_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k
 {
     morph_rect(src, dst, rows, cols, k, 0);
 }
+
+/* ---------------------------------------------------------------- blur ---- */
+
+static int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        else i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+void oat_blur_box(const uint8_t *src, uint8_t *dst, int rows, int cols, int k)
+{
+    size_t n = (size_t)rows * cols;
+    if (k <= 1) { if (dst != src) memmove(dst, src, n); return; }
+    const int a = k / 2;
+    const double scale = 1.0 / ((double)k * k);
+    int *rowsum = (int *)malloc(n * sizeof(int));
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            int s = 0;
+            for (int j = 0; j < k; j++) s += src[(size_t)y * cols + reflect101(x - a + j, cols)];
+            rowsum[(size_t)y * cols + x] = s;
+        }
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            int s = 0;
+            for (int j = 0; j < k; j++) s += rowsum[(size_t)reflect101(y - a + j, rows) * cols + x];
+            long r = lrint(s * scale);                 /* saturate_cast<uchar>(cvRound(.)) */
+            dst[(size_t)y * cols + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    free(rowsum);
+}

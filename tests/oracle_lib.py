@@ -85,6 +85,11 @@ def _load():
     lib.oat_detect_thresh.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(HsvParams), u8p, C.POINTER(Detection)]
     lib.oat_chain_step.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_double, C.POINTER(HsvParams),
                                    u8p, u8p, C.POINTER(Detection), C.c_int]
+    lib.oat_blur_box.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+    lib.oat_diff_create.restype = C.c_void_p
+    lib.oat_diff_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.oat_diff_destroy.argtypes = [C.c_void_p]
+    lib.oat_diff_detect.argtypes = [C.c_void_p, u8p, u8p, C.POINTER(Detection)]
     return lib
 
 
@@ -244,3 +249,30 @@ def chain_step(mog, frame, lr, p, nthreads=1):
     lib.oat_chain_step(mog.h, _p(frame), mog.rows, mog.cols, float(lr), C.byref(p),
                        _p(scratch), _p(thr), C.byref(d), int(nthreads))
     return d.as_dict(), thr
+
+
+def blur(img, k):
+    img = _c(img)
+    out = np.empty_like(img)
+    lib.oat_blur_box(_p(img), _p(out), img.shape[0], img.shape[1], int(k))
+    return out
+
+
+class Diff:
+    """posidet diff (DifferenceDetector) oracle."""
+
+    def __init__(self, rows, cols, diff_threshold=10, blur=2, min_area=0.0, max_area=float(np.finfo(np.float64).max)):
+        self.rows, self.cols = rows, cols
+        self.h = lib.oat_diff_create(rows, cols, diff_threshold, blur, min_area, max_area)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.oat_diff_destroy(self.h)
+            self.h = None
+
+    def detect(self, grey):
+        grey = _c(grey)
+        thr = np.empty((self.rows, self.cols), np.uint8)
+        d = Detection()
+        lib.oat_diff_detect(self.h, _p(grey), _p(thr), C.byref(d))
+        return d.as_dict(), thr

@@ -559,6 +559,33 @@ def test_roi_mask_fused_before_mog(A):
     _same_detection(got[1], want)
 
 
+@pytest.mark.parametrize("blur", [0, 2, 5, 22])
+def test_posidet_diff_parity(A, blur):
+    """posidet diff (DifferenceDetector.cpp:98-173): absdiff -> threshold -> blur -> siftContours, stateful."""
+    rows, cols, n = 90, 200, 2
+    rng = np.random.default_rng(40 + blur)
+    det = A.DifferenceDetector(rows, cols, diff_threshold=12, blur=blur, area=(2.0, 1e6), n_streams=n)
+    orcs = [O.Diff(rows, cols, 12, blur, 2.0, 1e6) for _ in range(n)]
+    base = [rng.integers(40, 90, (rows, cols)).astype(np.int16) for _ in range(n)]
+    hits = 0
+    for t in range(20):
+        for s in range(n):
+            f = np.clip(base[s] + rng.integers(-4, 5, (rows, cols)), 0, 255).astype(np.uint8)
+            x, y = 10 + 8 * t + 20 * s, 15 + 3 * t
+            f[y:y + 12, x:x + 20] = 220
+            if t % 7 == 3:
+                f[0:3, :] = 255; f[:, 0:2] = 255          # activity on the image border (reflect-101 ring)
+            got = det.detectPosition(f, stream=s)
+            want, thr = orcs[s].detect(f)
+            if t > 0:
+                assert ((det.read_mask(1, s) > 0)[1:-1, 1:-1] == (thr > 0)[1:-1, 1:-1]).all(), (t, s)
+            _same_detection(got, want, (t, s))
+            hits += got.position_valid
+    assert hits >= 30
+    with pytest.raises(A.OatGpuError):
+        A.DifferenceDetector(rows, cols, blur=23)
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135

@@ -136,3 +136,42 @@ def test_mog2_row_parallel_equals_serial():
         assert (o1 == o2).all() and (m1 == m2).all()
     for x, y in zip(a.state(), b.state()):
         assert (x == y).all()
+
+
+def test_blur_known_answers_and_dilation_equivalence():
+    """cv::blur semantics (DifferenceDetector.cpp:160-161) and the property the GPU path relies on:
+    for k <= 22 the box blur of a {0,255} image is non-zero exactly where the k x k dilation is,
+    except on the outermost ring (BORDER_REFLECT_101), which findContours zeroes anyway."""
+    img = np.zeros((7, 9), np.uint8)
+    img[3, 4] = 255
+    b3 = O.blur(img, 3)
+    assert b3[2:5, 3:6].tolist() == [[28] * 3] * 3 and b3.sum() == 28 * 9          # 255/9 = 28.33 -> 28
+    b2 = O.blur(img, 2)
+    assert b2[3:5, 4:6].tolist() == [[64, 64], [64, 64]]                            # 63.75 -> 64; window [x-1, x]
+    edge = np.zeros((5, 6), np.uint8)
+    edge[2, 1] = 255
+    assert O.blur(edge, 2)[2, 0] == 64          # reflect-101: pixel x=1 also feeds output x=0 (window [-1,0] -> {1,0})
+    rng = np.random.default_rng(5)
+    for k in (2, 3, 4, 7, 10, 22):
+        for _ in range(10):
+            h, w = int(rng.integers(k + 2, 50)), int(rng.integers(k + 2, 60))
+            im = (rng.random((h, w)) < 0.1).astype(np.uint8) * 255
+            b, d = O.blur(im, k) > 0, O.dilate(im, k) > 0
+            assert (b[1:-1, 1:-1] == d[1:-1, 1:-1]).all()
+            assert O.sift_contours(b.astype(np.uint8) * 255) == O.sift_contours(d.astype(np.uint8) * 255)
+    one = np.zeros((60, 60), np.uint8)
+    one[30, 30] = 255
+    assert O.blur(one, 22).max() == 1 and O.blur(one, 23).max() == 0            # why the GPU path stops at 22
+
+
+def test_diff_detector_first_frame_and_motion():
+    d = O.Diff(40, 50, diff_threshold=10, blur=2)
+    f0 = np.full((40, 50), 30, np.uint8)
+    r, thr = d.detect(f0)
+    assert (thr == f0).all() and r["valid"] and r["area"] == (50 - 3) * (40 - 3)   # first frame analysed as is
+    f1 = f0.copy()
+    f1[10:20, 15:30] = 200
+    r, thr = d.detect(f1)
+    assert r["valid"] and r["area"] == 15 * 10      # 15x10 box grown by the 2x2 blur -> 16x11 pixels -> (16-1)*(11-1)
+    r, thr = d.detect(f1)
+    assert not r["valid"] and thr.max() == 0        # nothing moved
