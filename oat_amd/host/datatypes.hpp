@@ -14,6 +14,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -132,6 +133,69 @@ static_assert(offsetof(Position2D, region) == 1 && offsetof(Position2D, position
               offsetof(Position2D, heading) == 48 && offsetof(Position2D, label_) == 64 &&
               offsetof(Position2D, unit_of_length_) == 164 && offsetof(Position2D, sample_) == 168 &&
               offsetof(Position2D, homography_) == 208, "oat::Position2D offsets");
+
+// ---- position wire formats (lib/datatypes/Position2D.cpp:24-96, Position2D.h:170-233) ----
+
+// numpy structured dtype of one packed record, 82 bytes (Position2D::NPY_DTYPE / NPY_DTYPE_BYTES)
+constexpr size_t kNpyDtypeBytes = 82;
+inline const char *npy_dtype()
+{
+    return "[('tick', '<u8'),('usec', '<u8'),('unit', '<i4'),('pos_ok', '<i1'),('pos_xy', 'f8', (2)),"
+           "('vel_ok', '<i1'),('vel_xy', 'f8', (2)),('head_ok', '<i1'),('head_xy', 'f8', (2)),"
+           "('reg_ok', '<i1'),('reg', 'a10')]";
+}
+
+// oat::packPosition (Position2D.cpp:37-96): the record the reference's recorder writes to .npy files
+inline std::vector<char> packPosition(const Position2D &p)
+{
+    std::vector<char> pack;
+    pack.reserve(kNpyDtypeBytes);
+    auto put = [&pack](const void *v, size_t n) { pack.insert(pack.end(), (const char *)v, (const char *)v + n); };
+    const uint64_t tick = p.sample_.count(), usec = (uint64_t)p.sample_.microseconds();
+    const int32_t unit = (int32_t)p.unit_of_length_;
+    const char pok = p.position_valid ? 1 : 0, vok = p.velocity_valid ? 1 : 0, hok = p.heading_valid ? 1 : 0,
+               rok = p.region_valid ? 1 : 0;
+    put(&tick, 8); put(&usec, 8); put(&unit, 4);
+    put(&pok, 1); put(&p.position.x, 8); put(&p.position.y, 8);
+    put(&vok, 1); put(&p.velocity.x, 8); put(&p.velocity.y, 8);
+    put(&hok, 1); put(&p.heading.x, 8); put(&p.heading.y, 8);
+    put(&rok, 1); put(p.region, Position2D::REGION_LEN);
+    return pack;
+}
+
+// oat::serializePosition (Position2D.h:170-233) with rapidjson's SetMaxDecimalPlaces(5) rendered by
+// truncation to 5 places minus trailing zeros -- same field set and order, same "only when valid" rule.
+inline std::string jsonNumber(double v)
+{
+    char buf[80];
+    snprintf(buf, sizeof buf, "%.9f", v);            // rapidjson TRUNCATES to 5 places, it does not round
+    std::string s(buf);
+    size_t dot = s.find('.');
+    if (dot != std::string::npos) s.erase(dot + 6);
+    if (dot != std::string::npos) {
+        size_t last = s.find_last_not_of('0');
+        s.erase(last == dot ? dot + 2 : last + 1);       // rapidjson keeps one digit after the point
+    }
+    return s;
+}
+inline std::string serializePosition(const Position2D &p, bool verbose = false)
+{
+    std::string o = "{\"tick\":" + std::to_string(p.sample_.count()) + ",\"usec\":" +
+                    std::to_string((unsigned long long)p.sample_.microseconds()) + ",\"unit\":" +
+                    std::to_string((int)p.unit_of_length_);
+    auto pair = [](const char *key, const Point2D &v) {
+        return std::string(",\"") + key + "\":[" + jsonNumber(v.x) + "," + jsonNumber(v.y) + "]";
+    };
+    o += std::string(",\"pos_ok\":") + ((p.position_valid || verbose) ? "true" : "false");
+    if (p.position_valid || verbose) o += pair("pos_xy", p.position);
+    o += std::string(",\"vel_ok\":") + ((p.velocity_valid || verbose) ? "true" : "false");
+    if (p.velocity_valid || verbose) o += pair("vel_xy", p.velocity);
+    o += std::string(",\"head_ok\":") + (p.heading_valid ? "true" : "false");
+    if (p.heading_valid || verbose) o += pair("head_xy", p.heading);
+    o += std::string(",\"reg_ok\":") + (p.region_valid ? "true" : "false");
+    if (p.region_valid || verbose) o += std::string(",\"reg\":\"") + p.region + "\"";
+    return o + "}";
+}
 
 // lib/shmemdf/SharedFrameHeader.h:31-37
 struct FrameParams {

@@ -239,8 +239,44 @@ static void concurrency_tests()
     scrub();
 }
 
+// Position wire formats (lib/datatypes/Position2D.cpp:24-96, Position2D.h:170-233)
+static void wire_tests(const char *npy_path)
+{
+    Position2D p("cam");
+    p.sample_.set_rate_hz(100.0);
+    p.sample_.incrementCount(); p.sample_.incrementCount();
+    p.position_valid = true; p.position.x = 6.0; p.position.y = 3.254901960784;
+    auto r = packPosition(p);
+    CHECK(r.size() == kNpyDtypeBytes && r.size() == 82);
+    uint64_t tick, usec; int32_t unit; double px, py;
+    memcpy(&tick, &r[0], 8); memcpy(&usec, &r[8], 8); memcpy(&unit, &r[16], 4);
+    memcpy(&px, &r[21], 8); memcpy(&py, &r[29], 8);
+    CHECK(tick == 2 && usec == 20000 && unit == 0 && r[20] == 1 && px == 6.0 && py == 3.254901960784);
+    CHECK(r[37] == 0 && r[54] == 0 && r[71] == 0);               // vel_ok, head_ok, reg_ok
+    CHECK(serializePosition(p) == "{\"tick\":2,\"usec\":20000,\"unit\":0,\"pos_ok\":true,\"pos_xy\":[6.0,3.2549],"
+                                  "\"vel_ok\":false,\"head_ok\":false,\"reg_ok\":false}");
+    p.position_valid = false;
+    CHECK(serializePosition(p) == "{\"tick\":2,\"usec\":20000,\"unit\":0,\"pos_ok\":false,\"vel_ok\":false,"
+                                  "\"head_ok\":false,\"reg_ok\":false}");
+    if (npy_path) {     // three records in a .npy file for numpy to read back (tests/test_host_pipeline.py)
+        FILE *f = fopen(npy_path, "wb");
+        std::string d = std::string("{'descr': ") + npy_dtype() + ", 'fortran_order': False, 'shape': (3,), }";
+        d += std::string((64 - (10 + d.size() + 1) % 64) % 64, ' ') + "\n";
+        uint16_t len = (uint16_t)d.size();
+        fwrite("\x93NUMPY\x01\x00", 1, 8, f); fwrite(&len, 2, 1, f); fwrite(d.data(), 1, d.size(), f);
+        for (int i = 0; i < 3; ++i) {
+            p.sample_.incrementCount();
+            p.position_valid = i != 1; p.position.x = 10.5 * i; p.position.y = -i;
+            auto rec = packPosition(p);
+            fwrite(rec.data(), 1, rec.size(), f);
+        }
+        fclose(f);
+    }
+}
+
 int main(int argc, char **argv)
 {
+    wire_tests(argc > 2 ? argv[2] : nullptr);
     ADDR = argc > 1 ? argv[1] : "oat_hip_test_" + std::to_string(getpid());
     node_tests();
     sink_tests();

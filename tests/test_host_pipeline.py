@@ -23,12 +23,21 @@ def host_bins():
     return BIN
 
 
-def test_shm_protocol_scenarios(host_bins):
-    """Reference test/shmemdf/*_test.cpp scenarios restated in oat_amd/host/test_shmemdf.cpp."""
-    out = subprocess.run([os.path.join(host_bins, "test_shmemdf"), "oat_t_" + uuid.uuid4().hex[:8]],
+def test_shm_protocol_scenarios_and_wire_formats(host_bins, tmp_path):
+    """Reference test/shmemdf/*_test.cpp scenarios restated in oat_amd/host/test_shmemdf.cpp, plus the
+    position wire formats: the JSON serialiser (Position2D.h:170-233) and the packed 82-byte record
+    (Position2D.cpp:24-96), which numpy must read back with the reference's NPY dtype."""
+    npy = tmp_path / "pos.npy"
+    out = subprocess.run([os.path.join(host_bins, "test_shmemdf"), "oat_t_" + uuid.uuid4().hex[:8], str(npy)],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures" in out.stdout
+    a = np.load(npy)
+    assert a.dtype.itemsize == 82 and a.dtype.names == ("tick", "usec", "unit", "pos_ok", "pos_xy", "vel_ok",
+                                                         "vel_xy", "head_ok", "head_xy", "reg_ok", "reg")
+    assert a["tick"].tolist() == [3, 4, 5] and a["usec"].tolist() == [30000, 40000, 50000]
+    assert a["pos_ok"].tolist() == [1, 0, 1] and a["pos_xy"].tolist() == [[0.0, 0.0], [10.5, -1.0], [21.0, -2.0]]
+    assert a["vel_ok"].tolist() == [0, 0, 0] and a["unit"].tolist() == [0, 0, 0]
 
 
 def test_binaries_exist_and_print_usage(host_bins):
