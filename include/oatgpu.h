@@ -135,6 +135,18 @@ int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_l
  * mask of that stream.  Applies to oatgpu_mog_apply / _filter and the fused track calls. */
 int oatgpu_set_roi_mask(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *roi_mask);
 
+/* BackgroundSubtractor::filter (`framefilt bsub`, src/framefilter/BackgroundSubtractor.cpp:87-100):
+ * the first frame of a camera stream becomes its background; alpha > 0 adapts it
+ * (cv::accumulateWeighted); out = in - background, saturating.  rows*cols*channels bytes; out may
+ * equal in. */
+int oatgpu_bsub_filter(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *frame_in, uint8_t *frame_out,
+                       double alpha);
+
+/* Threshold::filter (`framefilt thresh`, src/framefilter/Threshold.cpp:67-81): grey conversion for BGR
+ * contexts, inRange [i_min, i_max] (0..256), pixels outside are zeroed.  out may equal in. */
+int oatgpu_thresh_filter(oatgpu_ctx *ctx, const uint8_t *frame_in, uint8_t *frame_out, int32_t i_min,
+                         int32_t i_max);
+
 /* ---- stage-by-stage operators (host buffers), one call == one reference call ---- */
 
 /* cv::BackgroundSubtractorMOG2::apply(frame, mask, learning_rate)

@@ -9,8 +9,8 @@ by the tests and the benchmark; there is no CPU fallback -- importing
 """
 from .ffi import OatGpuError, lib_path  # noqa: F401
 from .components import (  # noqa: F401
-    BackgroundSubtractorMOG, ColorConvert, HSVDetector, SimpleThreshold, DifferenceDetector, HotPath, Position2D,
+    BackgroundSubtractorMOG, BackgroundSubtractor, Threshold, ColorConvert, HSVDetector, SimpleThreshold, DifferenceDetector, HotPath, Position2D,
 )
 
-__all__ = ["BackgroundSubtractorMOG", "ColorConvert", "HSVDetector", "SimpleThreshold", "DifferenceDetector", "HotPath",
+__all__ = ["BackgroundSubtractorMOG", "BackgroundSubtractor", "Threshold", "ColorConvert", "HSVDetector", "SimpleThreshold", "DifferenceDetector", "HotPath",
            "Position2D", "OatGpuError", "lib_path"]

@@ -136,6 +136,34 @@ class BackgroundSubtractorMOG(_Context):
         return mask
 
 
+class BackgroundSubtractor(_Context):
+    """framefilt bsub (BackgroundSubtractor.cpp): -a adaptation coefficient, first frame = background."""
+
+    def __init__(self, rows, cols, adaptation_coeff=0.0, **kw):
+        super().__init__(rows, cols, **kw)
+        self.alpha_ = float(adaptation_coeff)
+
+    def filter(self, frame, stream=0):
+        f = _frame(frame, self.frame_shape)
+        out = np.empty_like(f)
+        self._chk(self.lib.oatgpu_bsub_filter(self.ctx, stream, ffi.u8(f), ffi.u8(out), self.alpha_))
+        return out
+
+
+class Threshold(_Context):
+    """framefilt thresh (Threshold.cpp): -I [min,max] intensity passband."""
+
+    def __init__(self, rows, cols, intensity=(0, 256), **kw):
+        super().__init__(rows, cols, **kw)
+        self.i_min_, self.i_max_ = int(intensity[0]), int(intensity[1])
+
+    def filter(self, frame):
+        f = _frame(frame, self.frame_shape)
+        out = np.empty_like(f)
+        self._chk(self.lib.oatgpu_thresh_filter(self.ctx, ffi.u8(f), ffi.u8(out), self.i_min_, self.i_max_))
+        return out
+
+
 class ColorConvert(_Context):
     """framefilt col -C HSV."""
 

@@ -456,6 +456,57 @@ void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, cons
     hipLaunchKernelGGL(k_inrange_bits, dim3((nwords + 3) / 4), dim3(256), 0, st, g, frame, channels, rp, bits);
 }
 
+// framefilt bsub: first frame -> background; alpha > 0: cv::accumulateWeighted in fp32
+// (src*a + bg*b, a = (float)alpha, b = 1 - a) and convertTo(CV_8U) (round half even, saturate);
+// then frame - background, saturating (BackgroundSubtractor.cpp:87-100).
+__global__ __launch_bounds__(256) void k_bsub(const uint8_t *in, uint8_t *out, uint8_t *bg, float *bg_f, size_t n,
+                                              float a, float b, int first, int learn)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = in[i];
+        float f = first ? (float)v : bg_f[i];
+        int g = first ? v : bg[i];
+        if (learn) {
+            f = v * a + f * b;
+            g = min(255, max(0, __float2int_rn(f)));
+        }
+        if (first || learn) { bg_f[i] = f; bg[i] = (uint8_t)g; }
+        out[i] = (uint8_t)(v > g ? v - g : 0);
+    }
+}
+
+void launch_bsub(const uint8_t *in, uint8_t *out, uint8_t *bg, float *bg_f, size_t n, float a, float b, int first,
+                 int learn, hipStream_t st)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_bsub, dim3(blocks), dim3(256), 0, st, in, out, bg, bg_f, n, a, b, first, learn);
+}
+
+// framefilt thresh: RGB2Gray<uchar> ((1868 B + 9617 G + 4899 R + 8192) >> 14), inRange, setTo(0)
+__global__ __launch_bounds__(256) void k_thresh_filter(const uint8_t *in, uint8_t *out, size_t npx, int ch, int lo,
+                                                       int hi)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        if (ch == 3) {
+            const int b = in[3 * i], g = in[3 * i + 1], r = in[3 * i + 2];
+            const int y = (1868 * b + 9617 * g + 4899 * r + (1 << 13)) >> 14;
+            const bool keep = y >= lo && y <= hi;
+            out[3 * i] = keep ? b : 0; out[3 * i + 1] = keep ? g : 0; out[3 * i + 2] = keep ? r : 0;
+        } else {
+            const int y = in[i];
+            out[i] = (y >= lo && y <= hi) ? y : 0;
+        }
+    }
+}
+
+void launch_thresh_filter(const uint8_t *in, uint8_t *out, size_t npx, int channels, int lo, int hi, hipStream_t st)
+{
+    int blocks = (int)((npx + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_thresh_filter, dim3(blocks), dim3(256), 0, st, in, out, npx, channels, lo, hi);
+}
+
 // posidet diff: cv::absdiff + cv::threshold(THRESH_BINARY) of a GREY frame against the previous one
 // (DifferenceDetector.cpp:156-161), one wave = one mask word; also refreshes the previous frame.
 __global__ __launch_bounds__(256) void k_absdiff_bits(Geom g, const uint8_t *frame, uint8_t *last, int thr,

@@ -45,6 +45,9 @@ struct oatgpu_ctx {
     uint8_t *frames = nullptr;     // staging [n][H*W*3]
     uint8_t *aux_a = nullptr;      // [H*W*3]
     uint8_t *aux_b = nullptr;      // [H*W*3]
+    uint8_t *bsub_bg = nullptr;    // [n][H*W*ch] framefilt bsub background (u8) and its fp32 accumulator
+    float *bsub_f = nullptr;
+    std::vector<char> bsub_have;
     uint8_t *diff_last = nullptr;  // [n][H*W] previous GREY frame of posidet diff, allocated on first use
     std::vector<char> diff_have;   // per camera stream
     u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
@@ -149,7 +152,7 @@ static MogParams mogparams_of(const oatgpu_config &k)
 static void free_all(oatgpu_ctx *c)
 {
     if (!c) return;
-    hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
+    hipFree(c->bsub_bg); hipFree(c->bsub_f); hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
@@ -211,6 +214,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     const size_t n = cfg->n_streams, npx = (size_t)g.H * g.W, PA = g.Palloc, NW = PA / 64;
     c->nframes.assign(n, 0);
     c->diff_have.assign(n, 0);
+    c->bsub_have.assign(n, 0);
 
     bool ok = true;
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
@@ -442,6 +446,50 @@ extern "C" int oatgpu_mog_filter(oatgpu_ctx *c, int32_t s, const uint8_t *bgr_in
 {
     if (!bgr_out) return fail(c, OATGPU_E_INVALID, "null output frame");
     return mog_single(c, s, bgr_in, nullptr, bgr_out, lr);
+}
+
+extern "C" int oatgpu_bsub_filter(oatgpu_ctx *c, int32_t s, const uint8_t *in, uint8_t *out, double alpha)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (!(alpha >= 0.0 && alpha <= 1.0)) return fail(c, OATGPU_E_INVALID, "adaptation-coeff must be in [0,1]");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
+    const size_t nb = (size_t)c->g.H * c->g.W * c->cfg.channels;
+    if (!c->bsub_bg) {
+        HIPCHK(c, hipMalloc((void **)&c->bsub_bg, (size_t)c->cfg.n_streams * nb));
+        HIPCHK(c, hipMalloc((void **)&c->bsub_f, (size_t)c->cfg.n_streams * nb * sizeof(float)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    const float a = (float)alpha, b = 1 - a;              // accW_: AT a = (AT)alpha, b = 1 - a
+    launch_bsub(c->aux_a, c->aux_b, c->bsub_bg + (size_t)s * nb, c->bsub_f + (size_t)s * nb, nb, a, b,
+                c->bsub_have[s] ? 0 : 1, alpha > 0.0 ? 1 : 0, c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->bsub_have[s] = 1;
+    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_thresh_filter(oatgpu_ctx *c, const uint8_t *in, uint8_t *out, int32_t i_min, int32_t i_max)
+{
+    if (!c || !in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (i_min < 0 || i_min > 256 || i_max < 0 || i_max > 256)      // Threshold.cpp:62-63
+        return fail(c, OATGPU_E_INVALID, "Values of intensity should be between 0 and 256.");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = quiesce(c);
+    if (rc) return rc;
+    const size_t npx = (size_t)c->g.H * c->g.W, nb = npx * c->cfg.channels;
+    int lo, hi;
+    norm_range(i_min, i_max, lo, hi);
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    launch_thresh_filter(c->aux_a, c->aux_b, npx, c->cfg.channels, lo, hi, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
 }
 
 extern "C" int oatgpu_bgr2hsv(oatgpu_ctx *c, const uint8_t *bgr_in, uint8_t *hsv_out)

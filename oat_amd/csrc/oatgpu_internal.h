@@ -118,6 +118,11 @@ void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st
 // 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.
 void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
                          u64 *bits, hipStream_t st);
+// framefilt bsub (BackgroundSubtractor.cpp:87-100) on n = rows*cols*channels bytes of one stream
+void launch_bsub(const uint8_t *in, uint8_t *out, uint8_t *bg, float *bg_f, size_t n, float a, float b, int first,
+                 int learn, hipStream_t st);
+// framefilt thresh (Threshold.cpp:67-81): BGR->grey (channels 3) -> inRange -> setTo(0)
+void launch_thresh_filter(const uint8_t *in, uint8_t *out, size_t npx, int channels, int lo, int hi, hipStream_t st);
 // posidet diff front end of ONE frame: bits = |frame - last| > thr (or frame != 0 when !have_last); last = frame
 void launch_absdiff_bits(const Geom &g, const uint8_t *frame, uint8_t *last, int thr, int have_last, u64 *bits,
                          hipStream_t st);

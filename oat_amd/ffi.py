@@ -61,6 +61,8 @@ SIGNATURES = {
     "oatgpu_synchronize": (C.c_int, [_ctx]),
     "oatgpu_set_detector": (C.c_int, [_ctx] + [C.c_int32] * 8 + [C.c_double, C.c_double]),
     "oatgpu_set_roi_mask": (C.c_int, [_ctx, C.c_int32, _u8p]),
+    "oatgpu_bsub_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
+    "oatgpu_thresh_filter": (C.c_int, [_ctx, _u8p, _u8p, C.c_int32, C.c_int32]),
     "oatgpu_mog_apply": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_mog_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),

@@ -1,6 +1,8 @@
 // oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]
 //   TYPE  mog   MI355X replacement of `oat framefilt mog`  (src/framefilter/BackgroundSubtractorMOG.cpp)
 //         col   MI355X replacement of `oat framefilt col`  (src/framefilter/ColorConvert.cpp), BGR->HSV only
+//         bsub  MI355X replacement of `oat framefilt bsub` (src/framefilter/BackgroundSubtractor.cpp)
+//         thresh MI355X replacement of `oat framefilt thresh` (src/framefilter/Threshold.cpp)
 // Drop-in: same positional arguments, same option names (src/framefilter/main.cpp:91-296).
 #include "component.hpp"
 
@@ -57,18 +59,62 @@ protected:
     GpuCtx gpu_;
 };
 
+class BackgroundSubtractor : public FrameFilter {
+public:
+    using FrameFilter::FrameFilter;
+    double alpha_{0.0};             // BackgroundSubtractor.h
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        oatgpu_config cfg;
+        oatgpu_default_config(&cfg);
+        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
+        gpu_.create(cfg);
+    }
+    // BackgroundSubtractor.cpp:87-100 (a -f background image needs imread and is not supported)
+    void filter(Frame &frame) override
+    {
+        gpu_.check(oatgpu_bsub_filter(gpu_.ctx, 0, frame.data(), frame.data(), alpha_));
+    }
+    GpuCtx gpu_;
+};
+
+class Threshold : public FrameFilter {
+public:
+    using FrameFilter::FrameFilter;
+    int i_min_{0}, i_max_{256};     // Threshold.h
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        oatgpu_config cfg;
+        oatgpu_default_config(&cfg);
+        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
+        gpu_.create(cfg);
+    }
+    // Threshold.cpp:67-81
+    void filter(Frame &frame) override
+    {
+        gpu_.check(oatgpu_thresh_filter(gpu_.ctx, frame.data(), frame.data(), i_min_, i_max_));
+    }
+    GpuCtx gpu_;
+};
+
 static void usage()
 {
     std::cout << "Usage: oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]\n"
                  "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: BGR -> HSV colour conversion on an MI355X\n"
                  "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n      --gpu-index          HIP device ordinal\n"
-                 "col:  -C, --color             HSV\n";
+                 "col:  -C, --color             HSV\n"
+                 "bsub: -a, --adaptation-coeff  0..1, default 0 (static background = first frame)\n"
+                 "thresh: -I, --intensity       [min,max] in [0,256]\n";
 }
 
 int main(int argc, char **argv)
 {
     try {
-        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"h", "help"}}, {"help"});
+        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"I", "intensity"}, {"h", "help"}}, {"help"});
         if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
         const std::string type = o.positional[0];
         std::unique_ptr<Component> comp;
@@ -80,6 +126,20 @@ int main(int argc, char **argv)
         } else if (type == "col") {
             auto f = std::make_unique<ColorConvert>(o.positional[1], o.positional[2]);
             if (o.has("color") && o.kv["color"] != "HSV") throw std::runtime_error("only -C HSV is supported");
+            comp = std::move(f);
+        } else if (type == "bsub") {
+            auto f = std::make_unique<BackgroundSubtractor>(o.positional[1], o.positional[2]);
+            f->alpha_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);                // BackgroundSubtractor.cpp:75
+            if (o.has("background")) throw std::runtime_error("--background needs an image reader: not supported");
+            comp = std::move(f);
+        } else if (type == "thresh") {
+            auto f = std::make_unique<Threshold>(o.positional[1], o.positional[2]);
+            double a, b;
+            if (o.arr2("intensity", a, b)) {
+                if (a < 0 || a > 256 || b < 0 || b > 256)
+                    throw std::runtime_error("Values of intensity should be between 0 and 256.");   // Threshold.cpp:62-63
+                f->i_min_ = (int)a; f->i_max_ = (int)b;
+            }
             comp = std::move(f);
         } else {
             throw std::runtime_error("Selected TYPE is invalid.");

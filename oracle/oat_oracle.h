@@ -142,6 +142,23 @@ void oat_sift_contours(uint8_t *thr, int rows, int cols, double min_area, double
 void oat_sift_cracks(const uint8_t *thr, int rows, int cols, double min_area, double max_area,
                      oat_detection *out);
 
+/* ------------------------------------------------ sibling frame filters ---- */
+
+/* framefilt bsub, BackgroundSubtractor.cpp:71-100: first frame becomes the background (u8 + f32
+ * copies); alpha > 0: cv::accumulateWeighted (bg_f = src*a + bg_f*b in float, a = (float)alpha,
+ * b = 1 - a) then convertTo(CV_8U) (cvRound, saturate); frame = frame - background (saturating). */
+typedef struct oat_bsub oat_bsub;
+oat_bsub *oat_bsub_create(int rows, int cols, int channels, double alpha);
+void oat_bsub_destroy(oat_bsub *b);
+void oat_bsub_filter(oat_bsub *b, uint8_t *frame);
+
+/* cv::cvtColor(.., COLOR_BGR2GRAY) for 8U (RGB2Gray<uchar>: (1868 B + 9617 G + 4899 R + 8192) >> 14). */
+void oat_bgr2grey(const uint8_t *bgr, uint8_t *grey, size_t npixels);
+
+/* framefilt thresh, Threshold.cpp:67-81: grey conversion (BGR frames) -> inRange(i_min, i_max) ->
+ * frame.setTo(0, thresh == 0).  channels 3 (BGR) or 1 (GREY); in place. */
+void oat_thresh_filter(uint8_t *frame, size_t npixels, int channels, int i_min, int i_max);
+
 /* cv::blur(src, dst, Size(k,k)) on 8U: normalised box filter, anchor (k/2,k/2), BORDER_REFLECT_101,
  * dst = cvRound(sum * (1.0 / (k*k)))  (DifferenceDetector.cpp:160-161).  src/dst may alias. */
 void oat_blur_box(const uint8_t *src, uint8_t *dst, int rows, int cols, int k);

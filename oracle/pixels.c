@@ -193,3 +193,67 @@ void oat_blur_box(const uint8_t *src, uint8_t *dst, int rows, int cols, int k)
         }
     free(rowsum);
 }
+
+/* ------------------------------------------------ sibling frame filters ---- */
+
+struct oat_bsub {
+    int rows, cols, ch, set;
+    double alpha;
+    uint8_t *bg;
+    float *bg_f;
+};
+
+oat_bsub *oat_bsub_create(int rows, int cols, int channels, double alpha)
+{
+    oat_bsub *b = (oat_bsub *)calloc(1, sizeof(*b));
+    size_t n = (size_t)rows * cols * channels;
+    b->rows = rows; b->cols = cols; b->ch = channels; b->alpha = alpha;
+    b->bg = (uint8_t *)malloc(n);
+    b->bg_f = (float *)malloc(n * sizeof(float));
+    return b;
+}
+
+void oat_bsub_destroy(oat_bsub *b)
+{
+    if (!b) return;
+    free(b->bg); free(b->bg_f); free(b);
+}
+
+void oat_bsub_filter(oat_bsub *b, uint8_t *frame)
+{
+    size_t n = (size_t)b->rows * b->cols * b->ch;
+    if (!b->set) {                                  /* setBackgroundImage (BackgroundSubtractor.cpp:79-85) */
+        memcpy(b->bg, frame, n);
+        for (size_t i = 0; i < n; i++) b->bg_f[i] = (float)frame[i];
+        b->set = 1;
+    }
+    if (b->alpha > 0.0) {
+        const float a = (float)b->alpha, bb = 1 - a;    /* accW_<uchar,float>: AT a = (AT)alpha, b = 1 - a */
+        for (size_t i = 0; i < n; i++) {
+            b->bg_f[i] = frame[i] * a + b->bg_f[i] * bb;
+            long r = lrintf(b->bg_f[i]);                /* convertTo(CV_8U): saturate_cast<uchar>(cvRound) */
+            b->bg[i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+    for (size_t i = 0; i < n; i++)                      /* frame - background, saturating */
+        frame[i] = frame[i] > b->bg[i] ? (uint8_t)(frame[i] - b->bg[i]) : 0;
+}
+
+void oat_bgr2grey(const uint8_t *bgr, uint8_t *grey, size_t n)
+{
+    for (size_t i = 0; i < n; i++, bgr += 3)
+        grey[i] = (uint8_t)((1868 * bgr[0] + 9617 * bgr[1] + 4899 * bgr[2] + (1 << 13)) >> 14);
+}
+
+void oat_thresh_filter(uint8_t *frame, size_t n, int channels, int i_min, int i_max)
+{
+    int l, h;
+    inrange_bounds(i_min, i_max, &l, &h);
+    for (size_t i = 0; i < n; i++) {
+        int g = channels == 3
+            ? ((1868 * frame[3 * i] + 9617 * frame[3 * i + 1] + 4899 * frame[3 * i + 2] + (1 << 13)) >> 14)
+            : frame[i];
+        if (!(g >= l && g <= h))
+            for (int c = 0; c < channels; c++) frame[i * channels + c] = 0;
+    }
+}

@@ -85,6 +85,12 @@ def _load():
     lib.oat_detect_thresh.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(HsvParams), u8p, C.POINTER(Detection)]
     lib.oat_chain_step.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_double, C.POINTER(HsvParams),
                                    u8p, u8p, C.POINTER(Detection), C.c_int]
+    lib.oat_bsub_create.restype = C.c_void_p
+    lib.oat_bsub_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.oat_bsub_destroy.argtypes = [C.c_void_p]
+    lib.oat_bsub_filter.argtypes = [C.c_void_p, u8p]
+    lib.oat_bgr2grey.argtypes = [u8p, u8p, C.c_size_t]
+    lib.oat_thresh_filter.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
     lib.oat_blur_box.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
     lib.oat_diff_create.restype = C.c_void_p
     lib.oat_diff_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
@@ -276,3 +282,34 @@ class Diff:
         d = Detection()
         lib.oat_diff_detect(self.h, _p(grey), _p(thr), C.byref(d))
         return d.as_dict(), thr
+
+
+class Bsub:
+    """framefilt bsub oracle."""
+
+    def __init__(self, rows, cols, channels=3, alpha=0.0):
+        self.h = lib.oat_bsub_create(rows, cols, channels, float(alpha))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.oat_bsub_destroy(self.h)
+            self.h = None
+
+    def filter(self, frame):
+        f = _c(frame).copy()
+        lib.oat_bsub_filter(self.h, _p(f))
+        return f
+
+
+def bgr2grey(bgr):
+    bgr = _c(bgr)
+    out = np.empty(bgr.shape[:-1], np.uint8)
+    lib.oat_bgr2grey(_p(bgr), _p(out), out.size)
+    return out
+
+
+def thresh_filter(frame, i_min, i_max):
+    f = _c(frame).copy()
+    ch = 3 if f.ndim == 3 else 1
+    lib.oat_thresh_filter(_p(f), f.size // ch, ch, int(i_min), int(i_max))
+    return f

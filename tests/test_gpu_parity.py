@@ -586,6 +586,34 @@ def test_posidet_diff_parity(A, blur):
         A.DifferenceDetector(rows, cols, blur=23)
 
 
+@pytest.mark.parametrize("alpha,channels", [(0.0, 3), (0.05, 3), (0.3, 1), (1.0, 3)])
+def test_framefilt_bsub_parity(A, alpha, channels):
+    """framefilt bsub (BackgroundSubtractor.cpp:87-100): fp32 accumulateWeighted + saturating subtract."""
+    rows, cols = 37, 90
+    rng = np.random.default_rng(int(alpha * 100) + channels)
+    shape = (rows, cols, 3) if channels == 3 else (rows, cols)
+    g = A.BackgroundSubtractor(rows, cols, adaptation_coeff=alpha, channels=channels)
+    o = O.Bsub(rows, cols, channels, alpha)
+    base = rng.integers(0, 256, shape).astype(np.int16)
+    for t in range(40):
+        f = np.clip(base + rng.integers(-40, 41, shape) + (3 * t if t % 2 else 0), 0, 255).astype(np.uint8)
+        assert (g.filter(f) == o.filter(f)).all(), t
+
+
+def test_framefilt_thresh_parity(A):
+    """framefilt thresh (Threshold.cpp:67-81): BGR->grey (all 16.7M colours), inRange, setTo(0)."""
+    n = 4096
+    idx = np.arange(n * n, dtype=np.uint32)
+    bgr = np.stack([(idx & 255), (idx >> 8) & 255, (idx >> 16) & 255], -1).astype(np.uint8).reshape(n, n, 3)
+    for lo, hi in [(0, 256), (100, 180), (200, 100), (256, 256)]:
+        got = A.Threshold(n, n, intensity=(lo, hi)).filter(bgr)
+        assert (got == O.thresh_filter(bgr, lo, hi)).all(), (lo, hi)
+    grey = np.random.default_rng(1).integers(0, 256, (50, 70), dtype=np.uint8)
+    assert (A.Threshold(50, 70, intensity=(90, 160), channels=1).filter(grey) == O.thresh_filter(grey, 90, 160)).all()
+    with pytest.raises(A.OatGpuError):
+        A.Threshold(8, 8, intensity=(0, 300)).filter(np.zeros((8, 8, 3), np.uint8))      # Threshold.cpp:62-63
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135

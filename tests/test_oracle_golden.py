@@ -175,3 +175,21 @@ def test_diff_detector_first_frame_and_motion():
     assert r["valid"] and r["area"] == 15 * 10      # 15x10 box grown by the 2x2 blur -> 16x11 pixels -> (16-1)*(11-1)
     r, thr = d.detect(f1)
     assert not r["valid"] and thr.max() == 0        # nothing moved
+
+
+def test_grey_conversion_and_sibling_filters_known_answers():
+    """cv::cvtColor(BGR2GRAY) fixed point (R2Y 4899, G2Y 9617, B2Y 1868, shift 14), framefilt thresh and bsub."""
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 100]]], np.uint8)
+    # 0.114 B + 0.587 G + 0.299 R: blue 29, green 150, red 76; (1868*10 + 9617*200 + 4899*100 + 8192) >> 14 = 148
+    assert O.bgr2grey(px).tolist() == [[255, 0, 29, 150, 76, 148]]
+    out = O.thresh_filter(px, 30, 150)              # keeps grey in [30,150]: green(150), red(76), the last (148)
+    assert out[0].tolist() == [[0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 100]]
+    # bsub, alpha 0: first frame is the background -> zeros; later frames subtract it with saturation
+    b = O.Bsub(1, 3, 1, 0.0)
+    assert b.filter(np.array([[10, 100, 250]], np.uint8)).tolist() == [[0, 0, 0]]
+    assert b.filter(np.array([[5, 130, 255]], np.uint8)).tolist() == [[0, 30, 5]]
+    # alpha 0.5: bg_f = 0.5*frame + 0.5*bg_f; bg = cvRound (half to even): 10 -> (10+21)/2 = 15.5 -> 16
+    b = O.Bsub(1, 1, 1, 0.5)
+    assert b.filter(np.array([[10]], np.uint8)).tolist() == [[0]]
+    assert b.filter(np.array([[21]], np.uint8)).tolist() == [[21 - 16]]
+    assert b.filter(np.array([[21]], np.uint8)).tolist() == [[21 - 18]]      # 0.5*21 + 0.5*15.5 = 18.25 -> 18
