@@ -172,12 +172,17 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
 
 // RGB2HSV_b tables: sdiv[i] = cvRound((255<<12)/i), hdiv[i] = cvRound((180<<12)/(6 i)).
 // Neither quotient ever lands on .5 (255<<12 = 2^12*255, 180<<12/6 = 2^13*15), so
-// round-half-even == floor(q + 1/2) == (2n + i) / (2i) in integers.
+// round-half-even == floor(q + 1/2) == floor((2n + i) / (2i)).  The quotient is taken in fp32:
+// numerator < 2^22 and denominator <= 510 are exact floats, the correctly rounded quotient is off by
+// < 1/(4i) while the exact one is at least 1/(2i) away from the next integer, so floor() is exact
+// (checked against the integer form for all 255 entries in tests/test_abi_exports.py) -- and a float
+// division is ~4x cheaper than an integer one, which matters at two table entries per pixel.
 __device__ __forceinline__ void hsv_tables_init(int *sdiv, int *hdiv)
 {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        sdiv[i] = i ? (2 * (255 << 12) + i) / (2 * i) : 0;
-        hdiv[i] = i ? (2 * ((180 << 12) / 6) + i) / (2 * i) : 0;
+        const float d = (float)(2 * i);
+        sdiv[i] = i ? (int)floorf((float)(2 * (255 << 12) + i) / d) : 0;
+        hdiv[i] = i ? (int)floorf((float)(2 * ((180 << 12) / 6) + i) / d) : 0;
     }
 }
 
@@ -238,13 +243,11 @@ __global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaun
 {
     __shared__ int sdiv[256];
     __shared__ int hdiv[256];
-    hsv_tables_init(sdiv, hdiv);
-    __syncthreads();
 
     const int s = first_stream + blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kWavePx;
-    if (base >= g.P) return;                      // whole wave beyond the image (tail block)
+    const bool active = base < g.P;               // false: whole wave beyond the image (tail block)
 
     const size_t npx = (size_t)g.H * g.W;
     const uint8_t *frame = a.frames + (size_t)s * npx * CH;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaun
     int nmodes[kPX], nold[kPX];
 #pragma unroll
     for (int j = 0; j < kPX; ++j) nmodes[j] = 0;
-    if (!a.fresh) {
+    if (active && !a.fresh) {
         const vecb n4 = *(const vecb *)nm;
         const uint8_t *nb = (const uint8_t *)&n4;
 #pragma unroll
@@ -304,6 +307,12 @@ __global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaun
     }
     unsigned dvm = 0;           // modes whose variance/mean changed for any of the lane's pixels
     bool wchg = false;          // weights changed for any of the lane's pixels
+
+    // The HSV tables are built (integer divisions, LDS, one barrier) AFTER the model loads have
+    // been issued, so that their latency covers the table construction.
+    hsv_tables_init(sdiv, hdiv);
+    __syncthreads();
+    if (!active) return;
 
     u64 words[kPX];
 #pragma unroll

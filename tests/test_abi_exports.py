@@ -68,8 +68,10 @@ def test_create_without_gpu_fails_loudly_not_silently(lib):
 
 
 def test_hsv_table_integer_formula_equals_cvround():
-    """The kernel builds RGB2HSV_b's tables with (2n+i)/(2i); check against cvRound(n/i)."""
+    """The kernel builds RGB2HSV_b's tables as floor(fp32((2n+i) / (2i))): check that this equals the
+    integer form and cvRound(n/i) for every entry (the fp32 quotient is exact enough for floor())."""
     import numpy as np
     for i in range(1, 256):
-        assert (2 * (255 << 12) + i) // (2 * i) == int(np.rint((255 << 12) / (1.0 * i)))
-        assert (2 * ((180 << 12) // 6) + i) // (2 * i) == int(np.rint((180 << 12) / (6.0 * i)))
+        for n, ref in (((255 << 12), (255 << 12) / (1.0 * i)), ((180 << 12) // 6, (180 << 12) / (6.0 * i))):
+            q = int(np.floor(np.float32(2 * n + i) / np.float32(2 * i)))
+            assert q == (2 * n + i) // (2 * i) == int(np.rint(ref))
