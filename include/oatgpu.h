@@ -119,6 +119,15 @@ oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg);   /* NULL on failure; oatgp
 void oatgpu_destroy(oatgpu_ctx *ctx);
 const char *oatgpu_last_error(const oatgpu_ctx *ctx);
 
+/* Host-memory helpers for callers that do not link HIP themselves.  Frames handed to the
+ * stage-by-stage calls may live anywhere; when they live in page-locked memory (a shared-memory
+ * segment registered with oatgpu_host_register, or a buffer from oatgpu_host_alloc) the copies
+ * are direct DMA instead of bounce-buffered. */
+int oatgpu_host_register(void *ptr, size_t bytes);
+int oatgpu_host_unregister(void *ptr);
+void *oatgpu_host_alloc(size_t bytes);
+void oatgpu_host_free(void *ptr);
+
 /* HIP stream plumbing (hipStream_t passed as void*). */
 int oatgpu_set_stream(oatgpu_ctx *ctx, void *hip_stream);
 void *oatgpu_get_stream(oatgpu_ctx *ctx);

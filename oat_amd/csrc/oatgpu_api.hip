@@ -297,6 +297,26 @@ extern "C" const char *oatgpu_last_error(const oatgpu_ctx *c)
     return c ? c->err.c_str() : g_last_error.c_str();
 }
 
+extern "C" int oatgpu_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(nullptr, OATGPU_E_INVALID, "null argument");
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(nullptr, OATGPU_E_HIP, "hipHostRegister failed: %s", hipGetErrorString(e));
+    return OATGPU_OK;
+}
+extern "C" int oatgpu_host_unregister(void *ptr)
+{
+    if (!ptr) return OATGPU_E_INVALID;
+    return hipHostUnregister(ptr) == hipSuccess ? OATGPU_OK : OATGPU_E_HIP;
+}
+extern "C" void *oatgpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void oatgpu_host_free(void *ptr) { if (ptr) hipHostFree(ptr); }
+
 extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;

@@ -56,6 +56,10 @@ SIGNATURES = {
     "oatgpu_create": (_ctx, [C.POINTER(Config)]),
     "oatgpu_destroy": (None, [_ctx]),
     "oatgpu_last_error": (C.c_char_p, [_ctx]),
+    "oatgpu_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "oatgpu_host_unregister": (C.c_int, [C.c_void_p]),
+    "oatgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "oatgpu_host_free": (None, [C.c_void_p]),
     "oatgpu_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "oatgpu_get_stream": (C.c_void_p, [_ctx]),
     "oatgpu_synchronize": (C.c_int, [_ctx]),

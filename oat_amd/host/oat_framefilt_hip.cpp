@@ -28,6 +28,11 @@ protected:
     {
         gpu_.check(oatgpu_mog_filter(gpu_.ctx, 0, frame.data(), frame.data(), learning_coeff_));
     }
+    bool filter_from_shm(const Frame &in, Frame &out) override
+    {
+        gpu_.check(oatgpu_mog_filter(gpu_.ctx, 0, in.data(), out.data(), learning_coeff_));
+        return true;
+    }
     GpuCtx gpu_;
 };
 
@@ -56,6 +61,12 @@ protected:
         gpu_.check(oatgpu_bgr2hsv(gpu_.ctx, frame.data(), frame.data()));
         frame.set_color(PIX_HSV);
     }
+    bool filter_from_shm(const Frame &in, Frame &out) override
+    {
+        gpu_.check(oatgpu_bgr2hsv(gpu_.ctx, in.data(), out.data()));
+        out.set_color(PIX_HSV);
+        return true;
+    }
     GpuCtx gpu_;
 };
 
@@ -77,6 +88,11 @@ protected:
     {
         gpu_.check(oatgpu_bsub_filter(gpu_.ctx, 0, frame.data(), frame.data(), alpha_));
     }
+    bool filter_from_shm(const Frame &in, Frame &out) override
+    {
+        gpu_.check(oatgpu_bsub_filter(gpu_.ctx, 0, in.data(), out.data(), alpha_));
+        return true;
+    }
     GpuCtx gpu_;
 };
 
@@ -97,6 +113,11 @@ protected:
     void filter(Frame &frame) override
     {
         gpu_.check(oatgpu_thresh_filter(gpu_.ctx, frame.data(), frame.data(), i_min_, i_max_));
+    }
+    bool filter_from_shm(const Frame &in, Frame &out) override
+    {
+        gpu_.check(oatgpu_thresh_filter(gpu_.ctx, in.data(), out.data(), i_min_, i_max_));
+        return true;
     }
     GpuCtx gpu_;
 };

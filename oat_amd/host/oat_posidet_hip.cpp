@@ -28,6 +28,11 @@ protected:
         gpu_.create(cfg_);
     }
     // HSVDetector.cpp:142-173 / SimpleThreshold.cpp:114-134
+    bool detect_from_shm(const Frame &frame, Position2D &position) override
+    {
+        detectPosition(const_cast<Frame &>(frame), position);      // reads only
+        return true;
+    }
     void detectPosition(Frame &frame, Position2D &position) override
     {
         oatgpu_position r;

@@ -24,6 +24,11 @@ protected:
         cfg_.rows = (int)p.rows; cfg_.cols = (int)p.cols; cfg_.n_streams = 1;
         gpu_.create(cfg_);
     }
+    bool detect_from_shm(const Frame &frame, Position2D &position) override
+    {
+        detectPosition(const_cast<Frame &>(frame), position);      // reads only
+        return true;
+    }
     void detectPosition(Frame &frame, Position2D &position) override
     {
         const uint8_t *f = frame.data();
