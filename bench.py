@@ -264,6 +264,14 @@ def main():
     prof = hp.profile_read()
     hp.profile(0)
 
+    # achievable HBM rates of this very device (plain streaming kernels), rank 0 only, after the timed region
+    hbm_read = hbm_copy = None
+    if rank == 0:
+        try:
+            hbm_read, hbm_copy = hp.measure_hbm(1 << 30, 5)
+        except Exception as e:          # never let the probe break the benchmark line
+            log("hbm probe failed:", e)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +328,8 @@ def main():
                      "note": "achieved = ALGORITHMIC 205 B/px / K1 time; K1 skips planes of dead modes and "
                              "unchanged planes, so real traffic (PMC) is below algorithmic and frac may exceed 1",
                      "bytes_per_launch": BYTES_PER_PIXEL * px_per_launch, "avg_launch_ms": mog_ms,
+                     "measured_stream_read_GBps": hbm_read, "measured_stream_copy_GBps": hbm_copy,
+                     "traffic_GBps": (traffic / (mog_ms * 1e-3) / 1e9) if traffic else None,
                      "avg_launch_ms_raw_events": mog_ms_raw, "empty_event_pair_ms": prof["event_pair_ms"]},
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),

@@ -237,6 +237,12 @@ int oatgpu_profile_enable(oatgpu_ctx *ctx, int32_t on);
 int oatgpu_profile_read(oatgpu_ctx *ctx, oatgpu_profile *out);   /* synchronises */
 int oatgpu_profile_reset(oatgpu_ctx *ctx);
 
+/* Achievable HBM rates of THIS device, measured with plain streaming kernels (16 B/lane, `bytes`
+ * per buffer, best of `reps`): *read_gbps for a read-only sum, *copy_gbps for read+write of a copy
+ * (bytes moved = 2*bytes).  The spec peak (8 TB/s on MI355X) is never reached by any kernel; these
+ * are the ceilings the hot path is compared against besides the spec. */
+int oatgpu_measure_hbm(oatgpu_ctx *ctx, size_t bytes, int32_t reps, double *read_gbps, double *copy_gbps);
+
 #ifdef __cplusplus
 }
 #endif

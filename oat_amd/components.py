@@ -87,6 +87,12 @@ class _Context:
             m = _frame(mask, (self.rows, self.cols))
             self._chk(self.lib.oatgpu_set_roi_mask(self.ctx, stream, ffi.u8(m)))
 
+    def measure_hbm(self, nbytes=1 << 30, reps=5):
+        """(read_GBps, copy_GBps) of plain streaming kernels on this device."""
+        r, c = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.oatgpu_measure_hbm(self.ctx, int(nbytes), int(reps), C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     # -- taps ------------------------------------------------------------
     def read_mask(self, which=ffi.TAP_MORPH, stream=0):
         out = np.empty((self.rows, self.cols), np.uint8)

@@ -406,6 +406,30 @@ __global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaun
     }
 }
 
+// ---- achievable-bandwidth probes: the simplest possible streaming kernels ----
+__global__ __launch_bounds__(256) void k_stream_read(const uint4 *src, size_t n, unsigned *sink)
+{
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;          // keeps the loads alive, practically never taken
+}
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4 *src, uint4 *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)src, n16, sink);
+}
+void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
+}
+
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 

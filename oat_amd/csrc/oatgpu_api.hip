@@ -8,6 +8,7 @@
 #include "../../include/oatgpu.h"
 #include "oatgpu_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -856,6 +857,48 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
 }
 
 // ---------------------------------------------------------- measurement ----
+
+extern "C" int oatgpu_measure_hbm(oatgpu_ctx *c, size_t bytes, int32_t reps, double *read_gbps, double *copy_gbps)
+{
+    if (!c || bytes < (1u << 20) || reps < 1) return fail(c, OATGPU_E_INVALID, "bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = quiesce(c);
+    if (rc) return rc;
+    const size_t n16 = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    unsigned *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, n16 * 16);
+    if (e == hipSuccess) e = hipMalloc(&b, n16 * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&sink, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0x5a, n16 * 16, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, n16 * 16, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best_r = 0, best_c = 0;
+    for (int i = 0; i < reps + 1 && e == hipSuccess; ++i) {          // first iteration warms up
+        float ms = 0;
+        hipEventRecord(e0, c->stream);
+        launch_stream_read(a, n16, sink, c->stream);
+        hipEventRecord(e1, c->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && i && ms > 0)
+            best_r = std::max(best_r, (double)(n16 * 16) / (ms * 1e-3) / 1e9);
+        hipEventRecord(e0, c->stream);
+        launch_stream_copy(a, b, n16, c->stream);
+        hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && i && ms > 0)
+            best_c = std::max(best_c, (double)(2 * n16 * 16) / (ms * 1e-3) / 1e9);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(a); hipFree(b); hipFree(sink);
+    if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "bandwidth probe failed: %s", hipGetErrorString(e));
+    if (read_gbps) *read_gbps = best_r;
+    if (copy_gbps) *copy_gbps = best_c;
+    return OATGPU_OK;
+}
 
 extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
 {

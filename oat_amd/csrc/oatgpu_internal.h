@@ -113,6 +113,9 @@ struct MogLaunch {
 
 // --- kernels_mog.hip ---
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st);
+// plain streaming kernels for the achievable-bandwidth measurement (n16 = number of 16-byte elements)
+void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st);
+void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);
 void launch_nop(hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
 void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
 // 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.

@@ -84,6 +84,7 @@ SIGNATURES = {
     "oatgpu_profile_enable": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_profile_read": (C.c_int, [_ctx, C.POINTER(Profile)]),
     "oatgpu_profile_reset": (C.c_int, [_ctx]),
+    "oatgpu_measure_hbm": (C.c_int, [_ctx, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
