@@ -614,6 +614,62 @@ def test_framefilt_thresh_parity(A):
         A.Threshold(8, 8, intensity=(0, 300)).filter(np.zeros((8, 8, 3), np.uint8))      # Threshold.cpp:62-63
 
 
+def test_hot_path_random_configurations(A):
+    """Fuzz: random frame shapes, stream counts, learning rates, HSV windows, morphology sizes and area
+    windows through the fused chain, every frame checked against the oracle chain."""
+    from oat_amd.synth import SyntheticStream
+    rng = np.random.default_rng(2026)
+    for case in range(14):
+        rows, cols = int(rng.integers(20, 140)), int(rng.integers(20, 260))
+        n = int(rng.integers(1, 4))
+        rate = float(rng.choice([0.0, 0.005, 0.05, 0.5, -1.0]))
+        e, d = int(rng.choice([0, 0, 2, 3, 5])), int(rng.choice([0, 3, 7, 10, 16]))
+        h = sorted(rng.integers(0, 257, 2).tolist()) if case % 3 else [100, 125]
+        s_ = sorted(rng.integers(0, 257, 2).tolist()) if case % 4 == 0 else [0, 256]
+        v = [int(rng.integers(0, 120)), 256]
+        area = (float(rng.choice([0.0, 3.0, 30.0])), float(rng.choice([1e9, 500.0])))
+        hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=rate, h_thresh=h, s_thresh=s_, v_thresh=v,
+                       erode=e, dilate=d, area=area, ring_depth=int(rng.integers(1, 6)))
+        hp.learning_coeff_ = rate
+        p = O.hsv_params(h_lo=h[0], h_hi=h[1], s_lo=s_[0], s_hi=s_[1], v_lo=v[0], v_hi=v[1], erode=e, dilate=d,
+                         min_area=area[0], max_area=area[1])
+        streams = [SyntheticStream(rows, cols, 100 * case + s, n_discs=1 + s, radius=max(3, min(rows, cols) // 9),
+                                   noise=int(rng.integers(2, 20)), flicker=bool(case % 2)) for s in range(n)]
+        orcs = [O.Mog2(rows, cols, 3) for _ in range(n)]
+        for t in range(9):
+            frames = [st.frame(t, with_discs=t > 0) for st in streams]
+            got = hp.track(frames)
+            for s in range(n):
+                want, thr = O.chain_step(orcs[s], frames[s], rate, p)
+                assert (hp.read_mask(1, s) == thr).all(), (case, t, s)
+                _same_detection(got[s], want, (case, t, s))
+        for s in range(n):
+            _same_state(hp.mog_state(s), orcs[s].state(), (case, s))
+        hp.close()
+
+
+def test_two_contexts_interleaved_share_nothing(A):
+    """Two contexts (different geometry and parameters) used alternately in one process."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    win = disc_hsv_window()
+    cfgs = [dict(rows=96, cols=128, erode=0, dilate=5), dict(rows=70, cols=200, erode=3, dilate=0)]
+    hps, orcs, ps, sts = [], [], [], []
+    for i, c in enumerate(cfgs):
+        hps.append(A.HotPath(c["rows"], c["cols"], n_streams=1, adaptation_coeff=0.02, erode=c["erode"],
+                             dilate=c["dilate"], area=(3.0, 1e6), **win))
+        orcs.append(O.Mog2(c["rows"], c["cols"], 3))
+        ps.append(O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=c["erode"],
+                               dilate=c["dilate"], min_area=3.0, max_area=1e6))
+        sts.append(SyntheticStream(c["rows"], c["cols"], 50 + i, n_discs=1, radius=6))
+    for t in range(15):
+        for i in (0, 1, 1, 0)[: 2 + (t % 2)]:
+            f = sts[i].frame()
+            got = hps[i].track([f])[0]
+            want, thr = O.chain_step(orcs[i], f, 0.02, ps[i])
+            assert (hps[i].read_mask(1) == thr).all(), (t, i)
+            _same_detection(got, want, (t, i))
+
+
 def test_error_behaviour(A):
     with pytest.raises(A.OatGpuError):
         A.HSVDetector(10, 10, area=(5.0, 1.0))          # HSVDetector.cpp:135
