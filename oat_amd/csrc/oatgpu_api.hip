@@ -21,7 +21,8 @@ using namespace oatgpu;
 
 static thread_local std::string g_last_error;
 
-struct ProfStep { hipEvent_t e[5]; };   // A: K1 begin/end; B: back-half begin, after erode, end
+struct ProfStep { hipEvent_t e[5]; };
+struct Rate { float alphaT, alpha1, prune; int fresh; };   // A: K1 begin/end; B: back-half begin, after erode, end
 
 struct oatgpu_ctx {
     oatgpu_config cfg;
@@ -61,6 +62,7 @@ struct oatgpu_ctx {
     int ring_count = 0;
 
     std::vector<int> nframes;      // per camera stream
+    std::vector<Rate> rates_scratch;
 
     // profiling
     bool prof = false;
@@ -357,7 +359,6 @@ extern "C" int oatgpu_set_detector(oatgpu_ctx *c, int32_t h_lo, int32_t h_hi, in
 }
 
 // ---- BackgroundSubtractorMOG2Impl::apply prologue for one camera stream ----
-struct Rate { float alphaT, alpha1, prune; int fresh; };
 static Rate mog_begin(oatgpu_ctx *c, int s, double learningRate)
 {
     Rate r;
@@ -689,12 +690,22 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
     // analysing earlier frames' masks; it only has to wait for the back half that last read the
     // threshold buffer it is about to overwrite (four frames ago).
-    if (c->last_back[k]) HIPCHK(c, hipStreamWaitEvent(A, c->last_back[k], 0));
+    // (a stream wait costs ~5 us of host time; that back half has normally finished long ago, which
+    // a ~1 us event query on the host establishes just as well)
+    if (c->last_back[k]) {
+        if (hipEventQuery(c->last_back[k]) == hipSuccess) {
+            c->last_back[k] = nullptr;
+        } else {
+            (void)hipGetLastError();                 // hipErrorNotReady is not an error here
+            HIPCHK(c, hipStreamWaitEvent(A, c->last_back[k], 0));
+        }
+    }
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
     // every camera stream advances one frame; launches are batched while the streams share a
     // learning-rate schedule (they do unless the single-stage calls were used unevenly)
-    std::vector<Rate> rates(n);
+    std::vector<Rate> &rates = c->rates_scratch;
+    rates.resize(n);
     for (int s = 0; s < n; ++s) rates[s] = mog_begin(c, s, lr);
     int s0 = 0;
     while (s0 < n) {
