@@ -109,21 +109,82 @@ __device__ __forceinline__ u64 dilate_word(const Geom &g, const u64 *src, int y,
     return out & valid_bits(g, w);
 }
 
+// erosion of word (y, w) straight from the raw mask (same window rule as k_morph)
+__device__ __forceinline__ u64 erode_word(const Geom &g, const u64 *src, int y, int w, int k)
+{
+    const int a = k / 2;
+    const u64 vlast = valid_bits(g, g.words - 1);
+    u64 ap = ~0ull, ac = ~0ull, an = ~0ull;
+    for (int j = 0; j < k; ++j) {
+        const int yy = y - a + j;
+        if (yy < 0 || yy >= g.H) continue;
+        const u64 *row = src + (size_t)yy * g.words;
+        u64 cw = row[w];
+        u64 nw = (w + 1 < g.words) ? row[w + 1] : ~0ull;
+        if (w == g.words - 1) cw |= ~vlast;          // padding bits beyond x = W-1 read as 1
+        if (w + 1 == g.words - 1) nw |= ~vlast;
+        if (w > 0) ap &= row[w - 1];
+        ac &= cw;
+        an &= nw;
+    }
+    u64 out = ~0ull;
+    for (int j = 0; j < k; ++j) {
+        const int o = j - a;
+        out &= (o == 0) ? ac : (o > 0) ? ((ac >> o) | (an << (64 - o))) : ((ac << (-o)) | (ap >> (64 + o)));
+    }
+    return out & valid_bits(g, w);
+}
+
+// dilation of word (rr, w) out of a block-local stack of eroded rows in LDS: row j of the
+// window is er[(rr + j) * words + ...] (rows outside the image were stored as zeros)
+__device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int rr, int w, int k)
+{
+    const int a = k / 2;
+    u64 ap = 0, ac = 0, an = 0;
+    for (int j = 0; j < k; ++j) {
+        const u64 *row = er + (size_t)(rr + j) * g.words;
+        if (w > 0) ap |= row[w - 1];
+        ac |= row[w];
+        if (w + 1 < g.words) an |= row[w + 1];
+    }
+    u64 out = 0;
+    for (int j = 0; j < k; ++j) {
+        const int o = j - a;
+        out |= (o == 0) ? ac : (o > 0) ? ((ac >> o) | (an << (64 - o))) : ((ac << (-o)) | (ap >> (64 + o)));
+    }
+    return out & valid_bits(g, w);
+}
+
 // ------------------------------------------------------------- row scan ------
 // One wavefront per image row, one lane per mask word (rows wider than 4096 px
-// loop in chunks of 64 words).  Applies the dilation (dil_k > 1) on the fly,
-// writes the final mask (image frame zeroed, as cvStartFindContours does in
-// OpenCV 3.1), the run-start bits T, the start x of the run entering every
-// word, and initialises the union-find at run heads.
-__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int dil_k, BlobBuffers b,
+// loop in chunks of 64 words).  Applies the erosion (ERODE: the block first
+// erodes the 4 + dil_k - 1 rows its dilation windows touch into LDS) and the
+// dilation (dil_k > 1) on the fly, writes the final mask (image frame zeroed,
+// as cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start
+// x of the run entering every word, and initialises the union-find at run heads.
+template <bool ERODE>
+__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
                                                  int first_stream)
 {
+    extern __shared__ u64 er[];
     const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y >= g.H) return;
+    const int wave = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wave;
     const int s = first_stream + blockIdx.y;
-    const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     const u64 *src_img = src_all + (size_t)s * (g.Palloc >> 6);
+    const int dk = dil_k > 1 ? dil_k : 1;
+    if (ERODE) {
+        const int r0 = blockIdx.x * 4 - dk / 2;
+        const int n = (4 + dk - 1) * g.words;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int rr = i / g.words, w = i - rr * g.words;
+            const int yy = r0 + rr;
+            er[i] = (yy < 0 || yy >= g.H) ? 0ull : erode_word(g, src_img, yy, w, ero_k);
+        }
+        __syncthreads();
+    }
+    if (y >= g.H) return;
+    const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     u64 *morph = b.morph + woff;
     u64 *fin = b.fin + woff;
     u64 *trans = b.trans + woff;
@@ -141,9 +202,12 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
         const int w = c0 + lane;
         const bool active = w < g.words;
         u64 F = 0;
-        if (active && dil_k > 1) {
-            F = dilate_word(g, src_img, y, w, dil_k);
+        if (active && ERODE) {
+            F = dilate_word_lds(g, er, wave, w, dk);   // dk == 1: the eroded word itself
             morph[w] = F;                            // the reference's threshold_frame_ (parity tap)
+        } else if (active && dil_k > 1) {
+            F = dilate_word(g, src_img, y, w, dil_k);
+            morph[w] = F;
         } else if (active) {
             F = src_img[(size_t)y * g.words + w];
         }
@@ -495,11 +559,20 @@ __global__ __launch_bounds__(256) void k_green_select(Geom g, BlobBuffers b, dou
     }
 }
 
-void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int dil_k, double min_area,
+size_t rowscan_lds_bytes(const Geom &g, int dil_k)
+{
+    return (size_t)(4 + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64);
+}
+
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rowscan, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, dil_k, b,
-                       first_stream);
+    if (ero_k > 1)
+        hipLaunchKernelGGL(k_rowscan<true>, dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
+                           st, g, src_bits, ero_k, dil_k, b, first_stream);
+    else
+        hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
+                           dil_k, b, first_stream);
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);

@@ -556,16 +556,18 @@ static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int
     const u64 *src = thr;
     if (erode_k < 0) erode_k = c->cfg.erode;
     if (dilate_k < 0) dilate_k = c->cfg.dilate;
-    if (erode_k > 1) {
-        launch_morph(g, src, bb.tmp, erode_k, true, s0, n, st);
+    const int dil = dilate_k > 1 ? dilate_k : 0;
+    int ero = erode_k > 1 ? erode_k : 0;
+    if (ero && rowscan_lds_bytes(g, dil) > kRowscanLdsMax) {     // very wide rows x large dilation
+        launch_morph(g, src, bb.tmp, ero, true, s0, n, st);
         src = bb.tmp;
+        ero = 0;
     }
     if (ev_mid) HIPCHK(c, hipEventRecord(ev_mid, st));
-    const int dil = dilate_k > 1 ? dilate_k : 0;
-    c->last_morph = dil ? bb.morph : src;
+    c->last_morph = (dil || ero) ? bb.morph : src;
     c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, bb, src, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
+    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
     HIPCHK(c, hipGetLastError());
     return OATGPU_OK;
 }

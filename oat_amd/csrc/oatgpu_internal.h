@@ -162,9 +162,13 @@ struct ResultRec {   // device-side result, one per stream per step
 
 void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode, int first_stream,
                   int n_streams, hipStream_t st);
-// src_bits: mask before dilation; dil_k > 1 fuses the dilation into the row scan.
+// src_bits: mask before morphology; ero_k > 1 / dil_k > 1 fuse the erosion / dilation into the row
+// scan (the erosion through LDS: rowscan_lds_bytes() must stay under kRowscanLdsMax, otherwise the
+// caller erodes with launch_morph first and passes ero_k = 0).
 // results: device-visible (host-mapped) array indexed by stream.
-void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int dil_k, double min_area,
+constexpr size_t kRowscanLdsMax = 64 * 1024;
+size_t rowscan_lds_bytes(const Geom &g, int dil_k);
+void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st);
 
 }  // namespace oatgpu

@@ -476,9 +476,11 @@ def test_mog2_non_default_parameters(A):
     assert o.state()[0].max() == 3
 
 
-def test_wide_frame_and_large_kernels(A):
-    """W > 4096 (row scan loops over 64-word chunks), W not a multiple of 64, k up to 63."""
-    rows, cols = 70, 4300
+@pytest.mark.parametrize("cols", [4300, 8200])
+def test_wide_frame_and_large_kernels(A, cols):
+    """W > 4096 (row scan loops over 64-word chunks), W not a multiple of 64, k up to 63.  At 8200
+    columns the (5, 63) case exceeds the LDS budget of the fused erosion and takes the two-pass route."""
+    rows = 70
     rng = np.random.default_rng(33)
     det = A.SimpleThreshold(rows, cols, thresh=(1, 256))
     for e, d, dens in [(0, 0, 0.5), (5, 63, 0.9), (63, 0, 0.9997), (9, 33, 0.97)]:
