@@ -22,14 +22,23 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
-host: $(LIB)
+host: $(LIB) tools
 	$(MAKE) -C oat_amd/host
+
+# measurement aids: the pipelined loop from a plain C++ process, and a launch/event cost microbenchmark
+tools: build/bin/bench_native build/bin/launch_gap
+build/bin/bench_native: tools/bench_native.hip include/oatgpu.h $(LIB)
+	@mkdir -p build/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -w $< -Iinclude -Loat_amd/lib -loatgpu -Wl,-rpath,'$$ORIGIN/../../oat_amd/lib' -o $@
+build/bin/launch_gap: tools/launch_gap.hip
+	@mkdir -p build/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -w $< -o $@
 
 clean:
 	rm -f $(OBJS) $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle host clean
+.PHONY: all oracle host tools clean
 
 # A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> oat_amd/lib/liboatgpu_px2.so
 variant:

@@ -29,13 +29,16 @@ struct oatgpu_ctx {
     Geom g;
     hipStream_t stream = nullptr;   // stream A: uploads + the fused per-pixel kernel
     bool own_stream = false;
-    hipStream_t stream_b[2] = {nullptr, nullptr}; // streams B0/B1: morphology + blob analysis of even/odd frames,
+    static constexpr int kNB = 4;
+    int nb = 2;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
+    hipStream_t stream_b[kNB] = {}; // streams B0/B1: morphology + blob analysis of even/odd frames,
                                                   // overlapped with later frames' per-pixel kernels and each other
-    hipEvent_t ev_k1[2] = {nullptr, nullptr};    // K1 of parity q finished (thr[q] is ready)
+    hipEvent_t ev_k1[kNB] = {};    // K1 of parity q finished (thr[q] is ready)
     hipEvent_t last_back[4] = {nullptr, nullptr, nullptr, nullptr}; // ring event of the last back half that read thr[k]
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
     int ring_slots = 0;                               // internal ring size: ring_depth rounded up to a multiple of 4
     bool serial = false;
+    int expt = 0;
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
     int last_q = 0;
@@ -53,7 +56,7 @@ struct oatgpu_ctx {
     uint8_t *diff_last = nullptr;  // [n][H*W] previous GREY frame of posidet diff, allocated on first use
     std::vector<char> diff_have;   // per camera stream
     u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
-    BlobBuffers bb[2]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
+    BlobBuffers bb[kNB]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
     const u64 *last_morph = nullptr;
     const u64 *last_fin = nullptr;
     ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
@@ -163,7 +166,7 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.roots); hipFree(b.nroots);
     }
     if (c->res_host) hipHostFree(c->res_host);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
     }
     for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
@@ -227,16 +230,18 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         // bandwidth-bound launches of stream A: give it the highest priority
         int least = 0, greatest = 0;
         if (ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-        for (auto &sb : c->stream_b)
-            ok = ok && hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, greatest) == hipSuccess;
+        if (const char *e = getenv("OATGPU_NB")) { const int v = atoi(e); if (v >= 1 && v <= oatgpu_ctx::kNB) c->nb = v; }
+        for (int q = 0; q < c->nb; ++q)
+            ok = ok && hipStreamCreateWithPriority(&c->stream_b[q], hipStreamNonBlocking, greatest) == hipSuccess;
     }
+    c->expt = getenv("OATGPU_EXPT") ? atoi(getenv("OATGPU_EXPT")) : 0;   // measurement aid (bit mask)
     c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
     // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
     // six plain launches on MI355X / ROCm 7.2 (profiles/r01_d_*): opt-in only.
     c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
     c->ring_slots = (cfg->ring_depth + 3) / 4 * 4;    // slot & 3 = threshold buffer, slot & 1 = scratch set / stream
-    for (int q = 0; q < 2 && ok; ++q) {
-        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming) == hipSuccess;
+    for (int q = 0; q < c->nb && ok; ++q) {
+        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? hipEventDisableSystemFence : 0)) == hipSuccess;
     }
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
@@ -244,8 +249,9 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     A((void **)&c->aux_a, npx * 3);
     A((void **)&c->aux_b, npx * 3);
     A((void **)&c->bb[0].thr, 4 * n * NW * 8);       // four threshold-bit buffers: K1 runs up to 3 frames ahead
-    c->bb[1].thr = c->bb[0].thr;
-    for (auto &b : c->bb) {
+    for (int q = 0; q < c->nb; ++q) {
+        BlobBuffers &b = c->bb[q];
+        b.thr = c->bb[0].thr;
         A((void **)&b.tmp, n * NW * 8);
         A((void **)&b.morph, n * NW * 8);
         A((void **)&b.fin, n * NW * 8);
@@ -271,7 +277,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb[0].thr, 0, 4 * n * NW * 8, c->stream) != hipSuccess) ok = false;
-    for (auto &b : c->bb) {
+    for (int q = 0; q < c->nb; ++q) {
+        BlobBuffers &b = c->bb[q];
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     }
@@ -324,7 +331,7 @@ extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
+    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
@@ -335,7 +342,7 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
+    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
     return OATGPU_OK;
 }
 
@@ -385,7 +392,7 @@ static u64 *thr_buf(oatgpu_ctx *c, int parity)
 static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) HIPCHK(c, hipStreamSynchronize(sb));
+    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
     for (auto &e : c->last_back) e = nullptr;
     return OATGPU_OK;
 }
@@ -635,7 +642,7 @@ static void prof_fold(oatgpu_ctx *c)
 {
     if (!c->prof_used) return;
     hipStreamSynchronize(c->stream);
-    for (auto sb : c->stream_b) hipStreamSynchronize(sb);
+    for (auto sb : c->stream_b) if (sb) hipStreamSynchronize(sb);
     for (size_t i = 0; i < c->prof_used; ++i) {
         float a = 0, b = 0, d = 0, t = 0;
         ProfStep &p = c->prof_steps[i];
@@ -653,7 +660,7 @@ static void prof_fold(oatgpu_ctx *c)
 // into an executable graph: six dependent launches become one hipGraphLaunch of host work.
 static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
 {
-    const int q = slot & 1;
+    const int q = slot % c->nb;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(B, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
@@ -672,7 +679,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
     const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
-    const int q = slot & 1;                          // scratch set / B stream of this frame
+    const int q = slot % c->nb;                // scratch set / B stream of this frame
     const int k = slot & 3;                          // threshold-bit buffer of this frame
     hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
 
@@ -720,6 +727,13 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     }
     HIPCHK(c, hipGetLastError());
     if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
+    if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
+        HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
+        c->last_back[k] = nullptr;
+        c->enq_total++;
+        c->ring_count++;
+        return OATGPU_OK;
+    }
     HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
 
     // Stream B[q]: morphology + blob analysis of this frame.
