@@ -34,9 +34,8 @@ struct oatgpu_ctx {
     hipStream_t stream_b[kNB] = {}; // streams B0/B1: morphology + blob analysis of even/odd frames,
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[kNB] = {};    // K1 of parity q finished (thr[q] is ready)
-    hipEvent_t last_back[4] = {nullptr, nullptr, nullptr, nullptr}; // ring event of the last back half that read thr[k]
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
-    int ring_slots = 0;                               // internal ring size: ring_depth rounded up to a multiple of 4
+    int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
     int expt = 0;
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
@@ -239,16 +238,18 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
     // six plain launches on MI355X / ROCm 7.2 (profiles/r01_d_*): opt-in only.
     c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
-    c->ring_slots = (cfg->ring_depth + 3) / 4 * 4;    // slot & 3 = threshold buffer, slot & 1 = scratch set / stream
+    c->ring_slots = cfg->ring_depth;                  // slot = threshold buffer, slot % nb = scratch set / stream
     for (int q = 0; q < c->nb && ok; ++q) {
-        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? hipEventDisableSystemFence : 0)) == hipSuccess;
+        ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;
     }
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
     A((void **)&c->frames, n * npx * cfg->channels);
     A((void **)&c->aux_a, npx * 3);
     A((void **)&c->aux_b, npx * 3);
-    A((void **)&c->bb[0].thr, 4 * n * NW * 8);       // four threshold-bit buffers: K1 runs up to 3 frames ahead
+    // One threshold-bit buffer per ring slot: a slot is only reused after its result was collected,
+    // i.e. after the back half that read its buffer has finished -- stream A never waits for a B stream.
+    A((void **)&c->bb[0].thr, (size_t)c->ring_slots * n * NW * 8);
     for (int q = 0; q < c->nb; ++q) {
         BlobBuffers &b = c->bb[q];
         b.thr = c->bb[0].thr;
@@ -276,7 +277,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
-    if (ok && hipMemsetAsync(c->bb[0].thr, 0, 4 * n * NW * 8, c->stream) != hipSuccess) ok = false;
+    if (ok && hipMemsetAsync(c->bb[0].thr, 0, (size_t)c->ring_slots * n * NW * 8, c->stream) != hipSuccess) ok = false;
     for (int q = 0; q < c->nb; ++q) {
         BlobBuffers &b = c->bb[q];
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
@@ -393,7 +394,6 @@ static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
-    for (auto &e : c->last_back) e = nullptr;
     return OATGPU_OK;
 }
 
@@ -664,7 +664,7 @@ static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(B, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
-    const int rc = back_half(c, c->bb[q], thr_buf(c, slot & 3), 0, c->cfg.n_streams, slot, B, nullptr);
+    const int rc = back_half(c, c->bb[q], thr_buf(c, slot), 0, c->cfg.n_streams, slot, B, nullptr);
     const hipError_t e = hipStreamEndCapture(B, &graph);
     if (rc != OATGPU_OK || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); return nullptr; }
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
@@ -680,7 +680,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     const int n = c->cfg.n_streams;
     const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
     const int q = slot % c->nb;                // scratch set / B stream of this frame
-    const int k = slot & 3;                          // threshold-bit buffer of this frame
+    const int k = slot;                              // threshold-bit buffer of this frame
     hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
 
     ProfStep *ps = nullptr;
@@ -697,18 +697,8 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     }
 
     // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
-    // analysing earlier frames' masks; it only has to wait for the back half that last read the
-    // threshold buffer it is about to overwrite (four frames ago).
-    // (a stream wait costs ~5 us of host time; that back half has normally finished long ago, which
-    // a ~1 us event query on the host establishes just as well)
-    if (c->last_back[k]) {
-        if (hipEventQuery(c->last_back[k]) == hipSuccess) {
-            c->last_back[k] = nullptr;
-        } else {
-            (void)hipGetLastError();                 // hipErrorNotReady is not an error here
-            HIPCHK(c, hipStreamWaitEvent(A, c->last_back[k], 0));
-        }
-    }
+    // analysing earlier frames' masks.  It writes the threshold buffer of its own ring slot, whose
+    // previous reader finished before that slot's result was collected: nothing to wait for.
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
     // every camera stream advances one frame; launches are batched while the streams share a
@@ -729,7 +719,6 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
     if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
         HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
-        c->last_back[k] = nullptr;
         c->enq_total++;
         c->ring_count++;
         return OATGPU_OK;
@@ -746,7 +735,8 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         if (ps) { HIPCHK(c, hipEventRecord(ps->e[2], B)); HIPCHK(c, hipEventRecord(ps->e[3], B)); }
         HIPCHK(c, hipGraphLaunch(c->back_graph[slot], B));
         const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-        c->last_morph = dil ? c->bb[q].morph : (c->cfg.erode > 1 ? c->bb[q].tmp : thr_buf(c, k));
+        const bool ero = c->cfg.erode > 1, fused = ero && rowscan_lds_bytes(c->g, dil) <= kRowscanLdsMax;
+        c->last_morph = (dil || fused) ? c->bb[q].morph : (ero ? c->bb[q].tmp : thr_buf(c, k));
         c->last_fin = c->bb[q].fin;
     } else {
         if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
@@ -755,7 +745,6 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     }
     if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
-    c->last_back[k] = c->ring_ev[slot];
     c->last_q = k;
     c->enq_total++;
     c->ring_count++;
