@@ -230,6 +230,13 @@ int oatgpu_mog_set_state(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *mode
                          const float *weight, const float *variance, const float *mean,
                          int32_t nframes);
 
+/* MOG2 model checkpoint of one stream (the reference has none: a restarted `framefilt mog`
+ * relearns its background for ~history frames).  save writes PATH atomically (PATH.tmp + rename);
+ * load refuses a file whose geometry, channel count or mixture count differ from the context's.
+ * Resuming from a checkpoint continues bit-identically to an uninterrupted run. */
+int oatgpu_mog_save(oatgpu_ctx *ctx, int32_t stream_ix, const char *path);
+int oatgpu_mog_load(oatgpu_ctx *ctx, int32_t stream_ix, const char *path);
+
 /* ---- measurement ---- */
 /* on = 0: off; on = 1: time every step; on = N > 1: time every Nth step (each timed step costs
  * five hipEventRecord calls, ~20 us of host time -- sample when the host is the bottleneck). */

@@ -12,6 +12,7 @@ reference's call sites:
 All pixel work happens in liboatgpu.so on the GPU.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -115,6 +116,15 @@ class _Context:
         w, v, m = (np.ascontiguousarray(a, np.float32) for a in (w, v, m))
         self._chk(self.lib.oatgpu_mog_set_state(self.ctx, stream, ffi.u8(nm), ffi.f32(w), ffi.f32(v), ffi.f32(m),
                                                 int(nframes)))
+
+
+    def save_mog_state(self, path, stream=0):
+        """Checkpoint the MOG2 model of one stream to a file (oatgpu_mog_save)."""
+        self._chk(self.lib.oatgpu_mog_save(self.ctx, stream, os.fsencode(path)))
+
+    def load_mog_state(self, path, stream=0):
+        """Resume from a checkpoint; geometry / channels / mixture count must match."""
+        self._chk(self.lib.oatgpu_mog_load(self.ctx, stream, os.fsencode(path)))
 
 
 class BackgroundSubtractorMOG(_Context):

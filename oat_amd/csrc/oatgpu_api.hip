@@ -849,6 +849,8 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (!modes_used || !weight || !variance || !mean || nframes < 0)
         return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures, mb = 4 * (size_t)c->cfg.channels;
     uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
@@ -870,6 +872,86 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state import failed: %s", hipGetErrorString(e));
     c->nframes[s] = nframes;
     return OATGPU_OK;
+}
+
+// ------------------------------------------------------- model checkpoint ----
+// File: 64-byte header, then modes_used u8[npx], weight f32[npx*k], variance f32[npx*k],
+// mean f32[npx*k*channels] in the logical layout of oatgpu_mog_get_state; entries of unused modes
+// are written as zeros so that equal models give equal files.
+namespace {
+struct CkptHeader {
+    char magic[8];          // "OATMOG2\0"
+    uint32_t version;       // 1
+    uint32_t rows, cols, channels, nmixtures;
+    int32_t nframes;
+    uint64_t payload_bytes;
+    uint8_t reserved[24];
+};
+static_assert(sizeof(CkptHeader) == 64, "checkpoint header layout");
+const char kCkptMagic[8] = {'O', 'A', 'T', 'M', 'O', 'G', '2', 0};
+}  // namespace
+
+extern "C" int oatgpu_mog_save(oatgpu_ctx *c, int32_t s, const char *path)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!path || !*path) return fail(c, OATGPU_E_INVALID, "null path");
+    const size_t npx = (size_t)c->g.H * c->g.W, k = c->cfg.nmixtures, ch = c->cfg.channels;
+    std::vector<uint8_t> mu(npx);
+    std::vector<float> w(npx * k), v(npx * k), m(npx * k * ch);
+    int32_t nf = 0;
+    rc = oatgpu_mog_get_state(c, s, mu.data(), w.data(), v.data(), m.data(), &nf);
+    if (rc) return rc;
+    for (size_t p = 0; p < npx; ++p)
+        for (size_t j = mu[p]; j < k; ++j) {
+            w[p * k + j] = 0.f; v[p * k + j] = 0.f;
+            for (size_t q = 0; q < ch; ++q) m[(p * k + j) * ch + q] = 0.f;
+        }
+    CkptHeader h{};
+    memcpy(h.magic, kCkptMagic, 8);
+    h.version = 1; h.rows = c->g.H; h.cols = c->g.W; h.channels = (uint32_t)ch; h.nmixtures = (uint32_t)k;
+    h.nframes = nf;
+    h.payload_bytes = npx + (w.size() + v.size() + m.size()) * sizeof(float);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(c, OATGPU_E_INVALID, "cannot open '%s' for writing", tmp.c_str());
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(mu.data(), 1, npx, f) == npx &&
+              fwrite(w.data(), 4, w.size(), f) == w.size() && fwrite(v.data(), 4, v.size(), f) == v.size() &&
+              fwrite(m.data(), 4, m.size(), f) == m.size();
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path) == 0;      // readers never see a half-written file
+    if (!ok) { remove(tmp.c_str()); return fail(c, OATGPU_E_INVALID, "writing '%s' failed", path); }
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_mog_load(oatgpu_ctx *c, int32_t s, const char *path)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!path || !*path) return fail(c, OATGPU_E_INVALID, "null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(c, OATGPU_E_INVALID, "cannot open '%s'", path);
+    CkptHeader h{};
+    const size_t npx = (size_t)c->g.H * c->g.W, k = c->cfg.nmixtures, ch = c->cfg.channels;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != 1) {
+        fclose(f);
+        return fail(c, OATGPU_E_INVALID, "'%s' is not a MOG2 model checkpoint", path);
+    }
+    if (h.rows != (uint32_t)c->g.H || h.cols != (uint32_t)c->g.W || h.channels != ch || h.nmixtures != k ||
+        h.nframes < 0 || h.payload_bytes != npx + (2 * npx * k + npx * k * ch) * sizeof(float)) {
+        fclose(f);
+        return fail(c, OATGPU_E_INVALID, "checkpoint '%s' is %ux%ux%u with %u mixtures; this context is %dx%dx%d with %d",
+                    path, h.rows, h.cols, h.channels, h.nmixtures, c->g.H, c->g.W, (int)ch, (int)k);
+    }
+    std::vector<uint8_t> mu(npx);
+    std::vector<float> w(npx * k), v(npx * k), m(npx * k * ch);
+    const bool ok = fread(mu.data(), 1, npx, f) == npx && fread(w.data(), 4, w.size(), f) == w.size() &&
+                    fread(v.data(), 4, v.size(), f) == v.size() && fread(m.data(), 4, m.size(), f) == m.size();
+    fclose(f);
+    if (!ok) return fail(c, OATGPU_E_INVALID, "checkpoint '%s' is truncated", path);
+    for (size_t p = 0; p < npx; ++p)
+        if (mu[p] > k) return fail(c, OATGPU_E_INVALID, "checkpoint '%s' is corrupt (mode count %u)", path, mu[p]);
+    return oatgpu_mog_set_state(c, s, mu.data(), w.data(), v.data(), m.data(), h.nframes);
 }
 
 // ---------------------------------------------------------- measurement ----

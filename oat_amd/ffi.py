@@ -81,6 +81,8 @@ SIGNATURES = {
     "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),
     "oatgpu_mog_get_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.POINTER(C.c_int32)]),
     "oatgpu_mog_set_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.c_int32]),
+    "oatgpu_mog_save": (C.c_int, [_ctx, C.c_int32, C.c_char_p]),
+    "oatgpu_mog_load": (C.c_int, [_ctx, C.c_int32, C.c_char_p]),
     "oatgpu_profile_enable": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_profile_read": (C.c_int, [_ctx, C.POINTER(Profile)]),
     "oatgpu_profile_reset": (C.c_int, [_ctx]),

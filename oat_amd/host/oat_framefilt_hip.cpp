@@ -5,6 +5,7 @@
 //         thresh MI355X replacement of `oat framefilt thresh` (src/framefilter/Threshold.cpp)
 // Drop-in: same positional arguments, same option names (src/framefilter/main.cpp:91-296).
 #include "component.hpp"
+#include <unistd.h>
 
 using namespace oat;
 
@@ -13,6 +14,12 @@ public:
     using FrameFilter::FrameFilter;
     double learning_coeff_{0.0};    // BackgroundSubtractorMOG.h:76
     int gpu_index_{0};
+    std::string model_file_;        // --model-file: resume the MOG2 model from / checkpoint it to this file
+    ~BackgroundSubtractorMOG() override
+    {
+        if (!model_file_.empty() && gpu_.ctx && oatgpu_mog_save(gpu_.ctx, 0, model_file_.c_str()) != OATGPU_OK)
+            std::cerr << name() << ": " << oatgpu_last_error(gpu_.ctx) << std::endl;
+    }
 
 protected:
     void configure_for(const FrameParams &p) override
@@ -22,6 +29,8 @@ protected:
         oatgpu_default_config(&cfg);
         cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.n_streams = 1;
         gpu_.create(cfg);
+        if (!model_file_.empty() && access(model_file_.c_str(), R_OK) == 0)
+            gpu_.check(oatgpu_mog_load(gpu_.ctx, 0, model_file_.c_str()));
     }
     // BackgroundSubtractorMOG.cpp:114-127 (CPU-branch semantics: MOG2, shadows kept)
     void filter(Frame &frame) override
@@ -127,6 +136,7 @@ static void usage()
     std::cout << "Usage: oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]\n"
                  "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: BGR -> HSV colour conversion on an MI355X\n"
                  "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n      --gpu-index          HIP device ordinal\n"
+                 "      --model-file FILE    resume the background model from FILE if it exists; checkpoint it there on exit\n"
                  "col:  -C, --color             HSV\n"
                  "bsub: -a, --adaptation-coeff  0..1, default 0 (static background = first frame)\n"
                  "thresh: -I, --intensity       [min,max] in [0,256]\n";
@@ -143,6 +153,7 @@ int main(int argc, char **argv)
             auto f = std::make_unique<BackgroundSubtractorMOG>(o.positional[1], o.positional[2]);
             f->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);     // BackgroundSubtractorMOG.cpp:86-88
             f->gpu_index_ = (int)o.num("gpu-index", 0, 0, 64);
+            if (o.has("model-file")) f->model_file_ = o.kv["model-file"];
             comp = std::move(f);
         } else if (type == "col") {
             auto f = std::make_unique<ColorConvert>(o.positional[1], o.positional[2]);

@@ -4,6 +4,7 @@
 // in, carrying the frame's Sample -- PositionDetector.cpp:80).  Options are the union of the
 // three stock components' (-a is mog's adaptation coefficient; the detector's area is --area).
 #include "component.hpp"
+#include <unistd.h>
 
 using namespace oat;
 
@@ -17,12 +18,20 @@ public:
     }
     oatgpu_config cfg_;
     double learning_coeff_{0.0};
+    std::string model_file_;        // --model-file: resume the MOG2 model from / checkpoint it to this file
+    ~FusedTracker() override
+    {
+        if (!model_file_.empty() && gpu_.ctx && oatgpu_mog_save(gpu_.ctx, 0, model_file_.c_str()) != OATGPU_OK)
+            std::cerr << name() << ": " << oatgpu_last_error(gpu_.ctx) << std::endl;
+    }
 
 protected:
     void configure_for(const FrameParams &p) override
     {
         cfg_.rows = (int)p.rows; cfg_.cols = (int)p.cols; cfg_.n_streams = 1;
         gpu_.create(cfg_);
+        if (!model_file_.empty() && access(model_file_.c_str(), R_OK) == 0)
+            gpu_.check(oatgpu_mog_load(gpu_.ctx, 0, model_file_.c_str()));
     }
     bool detect_from_shm(const Frame &frame, Position2D &position) override
     {
@@ -47,7 +56,7 @@ int main(int argc, char **argv)
             {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
              {"d", "dilate"}, {"h", "help"}}, {"help"});
         if (o.has("help") || o.positional.size() != 2) {
-            std::cout << "Usage: oat-track-hip SOURCE SINK [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n";
+            std::cout << "Usage: oat-track-hip SOURCE SINK [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]] [--model-file FILE]\n";
             return o.has("help") ? 0 : -1;
         }
         auto t = std::make_unique<FusedTracker>(o.positional[0], o.positional[1]);
@@ -59,6 +68,7 @@ int main(int argc, char **argv)
         if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
         if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
         if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }
+        if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
         return t->run();
     } catch (const std::exception &e) {
         std::cerr << "oat-track-hip: " << e.what() << std::endl;

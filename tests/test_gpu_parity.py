@@ -141,6 +141,63 @@ def test_mog_state_roundtrip_and_resume(A):
         assert (a.apply(f) == b.apply(f)).all()
 
 
+@pytest.mark.parametrize("channels", [3, 1])
+def test_mog_checkpoint_file_resumes_bit_identically(A, tmp_path, channels):
+    """oatgpu_mog_save / _load: a run resumed from the file equals the uninterrupted run AND the
+    oracle (masks and full model); equal models give byte-identical files; mismatching or damaged
+    files are refused."""
+    rng = np.random.default_rng(15)
+    rows, cols, n = 37, 101, 2
+    shape = (n, rows, cols, 3) if channels == 3 else (n, rows, cols)
+    frames = [np.clip(100 + rng.normal(0, 12, shape), 0, 255).astype(np.uint8) for _ in range(14)]
+    kw = dict(n_streams=n, channels=channels, adaptation_coeff=0.03, dilate=0)
+    if channels == 1:
+        kw.update(h_thresh=(1, 256))
+    a = A.HotPath(rows, cols, **kw)
+    o = [O.Mog2(rows, cols, channels=channels) for _ in range(n)]
+    for f in frames[:8]:
+        a.track(list(f))
+        for s in range(n):
+            o[s].apply(f[s], 0.03)
+    files = [str(tmp_path / f"s{s}.mog") for s in range(n)]
+    for s in range(n):
+        a.save_mog_state(files[s], stream=s)
+    a.save_mog_state(str(tmp_path / "again.mog"), stream=0)
+    assert open(files[0], "rb").read() == open(tmp_path / "again.mog", "rb").read()
+    assert os.path.getsize(files[0]) == 64 + rows * cols * (1 + 4 * 5 * (2 + channels))
+
+    b = A.HotPath(rows, cols, **kw)
+    for s in range(n):
+        b.load_mog_state(files[s], stream=s)
+    for f in frames[8:]:
+        ra, rb = a.track(list(f)), b.track(list(f))
+        for s in range(n):
+            o[s].apply(f[s], 0.03)
+            assert ra[s] == rb[s]
+            assert (a.read_mask(0, stream=s) == b.read_mask(0, stream=s)).all()
+    for s in range(n):
+        nm, w, v, m, nf = b.mog_state(stream=s)
+        onm, ow, ov, om = o[s].state()
+        live = np.arange(5)[None, :] < nm[:, None]
+        assert nf == 14 and (nm == onm.ravel()).all()
+        assert (w[live] == ow.reshape(-1, 5)[live]).all() and (v[live] == ov.reshape(-1, 5)[live]).all()
+        assert (m[live] == om.reshape(-1, 5, channels)[live]).all()
+
+    with pytest.raises(A.OatGpuError, match="is 37x101"):
+        A.HotPath(rows, cols + 1, **kw).load_mog_state(files[0])
+    with pytest.raises(A.OatGpuError, match="with 5 mixtures"):
+        A.HotPath(rows, cols, nmixtures=3, **kw).load_mog_state(files[0])
+    blob = open(files[0], "rb").read()
+    (tmp_path / "short.mog").write_bytes(blob[:-5])
+    with pytest.raises(A.OatGpuError):
+        b.load_mog_state(str(tmp_path / "short.mog"))
+    (tmp_path / "junk.mog").write_bytes(b"not a checkpoint" * 10)
+    with pytest.raises(A.OatGpuError, match="not a MOG2 model checkpoint"):
+        b.load_mog_state(str(tmp_path / "junk.mog"))
+    with pytest.raises(A.OatGpuError):
+        b.load_mog_state(str(tmp_path / "missing.mog"))
+
+
 # --------------------------------------------------------------- morphology --
 
 @pytest.mark.parametrize("shape", [(40, 64), (35, 130), (9, 7), (64, 200)])

@@ -67,7 +67,7 @@ def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
     subprocess.run([os.path.join(host_bins, "oat-clean-hip"), addr], capture_output=True)
 
 
-def _run_pipeline(host_bins, tmp_path, frames, fused):
+def _run_pipeline(host_bins, tmp_path, frames, fused, mog_args=()):
     rows, cols = frames[0].shape[:2]
     raw = tmp_path / "frames.raw"
     np.stack(frames).tofile(raw)
@@ -78,11 +78,11 @@ def _run_pipeline(host_bins, tmp_path, frames, fused):
     B = lambda n: os.path.join(host_bins, n)
     reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
     if fused:
-        procs.append(subprocess.Popen([B("oat-track-hip"), a_raw, a_pos, "-a", "0.01", "--area", "[20,100000]"] + det))
+        procs.append(subprocess.Popen([B("oat-track-hip"), a_raw, a_pos, "-a", "0.01", "--area", "[20,100000]"] + det + list(mog_args)))
     else:
         procs.append(subprocess.Popen([B("oat-posidet-hip"), "hsv", a_hsv, a_pos, "-a", "[20,100000]"] + det))
         procs.append(subprocess.Popen([B("oat-framefilt-hip"), "col", a_filt, a_hsv, "-C", "HSV"]))
-        procs.append(subprocess.Popen([B("oat-framefilt-hip"), "mog", a_raw, a_filt, "-a", "0.01"]))
+        procs.append(subprocess.Popen([B("oat-framefilt-hip"), "mog", a_raw, a_filt, "-a", "0.01"] + list(mog_args)))
     time.sleep(3.0)          # every consumer has touch()ed its node before the first token exists
     feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols",
                                str(cols), "-n", str(len(frames)), "-r", "200"])
@@ -122,3 +122,32 @@ def test_component_pipeline_matches_oracle(host_bins, tmp_path, fused):
             hits += 1
             assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, t
     assert hits >= n - 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_model_file_resumes_across_process_restarts(host_bins, tmp_path, fused):
+    """--model-file: the pipeline is stopped after 12 frames and started again; the restarted
+    processes continue from the checkpointed MOG2 model exactly where the oracle (never stopped) is."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 24
+    st = SyntheticStream(rows, cols, 5, n_discs=1)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(n)]
+    model = tmp_path / "bg.mog"
+    args = ["--model-file", str(model)]
+    got = _run_pipeline(host_bins, tmp_path, frames[:12], fused, args)
+    assert model.exists() and model.stat().st_size == 64 + rows * cols * 101
+    got += _run_pipeline(host_bins, tmp_path, frames[12:], fused, args)
+    assert len(got) == n
+    orc = O.Mog2(rows, cols, 3)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    hits = 0
+    for t, (f, g) in enumerate(zip(frames, got)):
+        want, _ = O.chain_step(orc, f, 0.01, p)
+        assert g["pos_ok"] == want["valid"], t
+        if want["valid"]:
+            hits += 1
+            assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, t
+    assert hits >= n - 3
