@@ -8,7 +8,7 @@ ARCH     ?= gfx950
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result -Wno-unused-value
 CSRC     = oat_amd/csrc
 LIB      = oat_amd/lib/liboatgpu.so
-OBJS     = $(CSRC)/kernels_mog.o $(CSRC)/kernels_blob.o $(CSRC)/oatgpu_api.o
+OBJS     = $(CSRC)/kernels_mog.o $(CSRC)/kernels_blob.o $(CSRC)/kernels_kalman.o $(CSRC)/oatgpu_api.o
 
 all: $(LIB) oracle
 
@@ -43,6 +43,6 @@ clean:
 # A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> oat_amd/lib/liboatgpu_px2.so
 variant:
 	@mkdir -p build/$(NAME) oat_amd/lib
-	for f in kernels_mog kernels_blob oatgpu_api; do $(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
+	for f in kernels_mog kernels_blob kernels_kalman oatgpu_api; do $(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o oat_amd/lib/liboatgpu_$(NAME).so build/$(NAME)/*.o
 .PHONY: variant

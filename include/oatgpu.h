@@ -93,6 +93,12 @@ typedef struct oatgpu_position {
     double x, y;               /* Position2D::position (pixels)               */
     double area;               /* siftContours' area out-parameter            */
     int64_t a00, a10, a01;     /* exact contour sums (cv::moments internals)  */
+    /* With oatgpu_set_kalman on (fused track calls only), valid/x/y above are what
+     * `posifilt kalman` would hand downstream (Position2D::position_valid/position) and: */
+    int32_t velocity_valid;    /* Position2D::velocity_valid (0 when the filter is off) */
+    int32_t raw_valid;         /* the detector's own position_valid              */
+    double vx, vy;             /* Position2D::velocity (position units / s)      */
+    double raw_x, raw_y;       /* the detector's own centroid                    */
 } oatgpu_position;
 
 /* Per-stage device time accumulated while profiling is enabled (HIP events on
@@ -138,6 +144,16 @@ int oatgpu_synchronize(oatgpu_ctx *ctx);
 int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
                         int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
                         double min_area, double max_area);
+
+/* `posifilt kalman` (src/positionfilter/KalmanFilter2D.cpp:63-141) applied to every stream's
+ * detections inside the fused track calls (oatgpu_track_batch/_dev/_enqueue_dev), on the device,
+ * in frame order.  dt: --dt (s, default 0.02); timeout: --timeout (s, default 0 -- with which the
+ * reference's filter never tracks); sigma_accel: --sigma-accel (default 5); sigma_noise:
+ * --sigma-noise (default 0).  All must be >= 0 and dt > 0 (TOMLSanitize lower bound 0).  Calling it
+ * (re)starts every stream's filter from the reference's initial state; enable = 0 turns it off.
+ * The single-stage oatgpu_detect_* calls are never filtered. */
+int oatgpu_set_kalman(oatgpu_ctx *ctx, int32_t enable, double dt, double timeout, double sigma_accel,
+                      double sigma_noise);
 
 /* `framefilt mask` fused in front of mog (src/framefilter/FrameMasker.cpp:71-75:
  * frame.setTo(0, roi_mask == 0)): roi_mask is rows*cols bytes, nonzero = keep; NULL removes the

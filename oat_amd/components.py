@@ -33,10 +33,17 @@ class Position2D:
     a10: int = 0
     a01: int = 0
     first_pixel: int = -1
+    velocity_valid: bool = False   # set by the position filter (HotPath.set_kalman)
+    vx: float = 0.0
+    vy: float = 0.0
+    raw_valid: bool = False        # the detector's own result when the filter is on
+    raw_x: float = 0.0
+    raw_y: float = 0.0
 
     @staticmethod
     def from_c(p):
-        return Position2D(bool(p.valid), p.x, p.y, p.area, p.a00, p.a10, p.a01, p.first_pixel)
+        return Position2D(bool(p.valid), p.x, p.y, p.area, p.a00, p.a10, p.a01, p.first_pixel,
+                          bool(p.velocity_valid), p.vx, p.vy, bool(p.raw_valid), p.raw_x, p.raw_y)
 
 
 def _frame(a, shape):
@@ -291,6 +298,11 @@ class HotPath(_Context):
 
     def outstanding(self):
         return self.lib.oatgpu_track_outstanding(self.ctx)
+
+    def set_kalman(self, enable=True, dt=0.02, timeout=0.0, sigma_accel=5.0, sigma_noise=0.0):
+        """`posifilt kalman` on the batch (KalmanFilter2D.cpp:63-141; option names and defaults are the
+        reference's).  (Re)starts every stream's filter."""
+        self._chk(self.lib.oatgpu_set_kalman(self.ctx, int(bool(enable)), dt, timeout, sigma_accel, sigma_noise))
 
     def set_stream(self, hip_stream):
         self._chk(self.lib.oatgpu_set_stream(self.ctx, C.c_void_p(hip_stream)))

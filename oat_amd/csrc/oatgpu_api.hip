@@ -37,8 +37,12 @@ struct oatgpu_ctx {
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
+    KalmanLaunch kal{};              // kal.state == nullptr: position filter off
+    bool kal_on = false;
+    unsigned kal_ticket = 0;         // ticket of the next enqueued frame
     int expt = 0;
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
+    std::vector<char> slot_filtered;                  // [ring_slots] was the position filter applied to this slot?
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
     int last_q = 0;
     std::string err;
@@ -159,6 +163,7 @@ static void free_all(oatgpu_ctx *c)
     if (!c) return;
     hipFree(c->bsub_bg); hipFree(c->bsub_f); hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
+    hipFree(c->kal.state);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
@@ -271,6 +276,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok) {
         c->ring_ev.resize(c->ring_slots);
         c->back_graph.assign(c->ring_slots, nullptr);
+        c->slot_filtered.assign(c->ring_slots, 0);
         for (auto &e : c->ring_ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
     }
@@ -440,6 +446,27 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     return OATGPU_OK;
 }
 
+extern "C" int oatgpu_set_kalman(oatgpu_ctx *c, int32_t enable, double dt, double timeout, double sigma_accel,
+                                 double sigma_noise)
+{
+    if (!c) return OATGPU_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "set_kalman while enqueued results are outstanding");
+    int rc = quiesce(c);
+    if (rc) return rc;
+    if (!enable) { c->kal_on = false; return OATGPU_OK; }
+    if (!(dt > 0) || !(timeout >= 0) || !(sigma_accel >= 0) || !(sigma_noise >= 0) || !(timeout / dt < 2147483647.0))
+        return fail(c, OATGPU_E_INVALID, "kalman: dt must be > 0, timeout / sigma-accel / sigma-noise >= 0");
+    if (!c->kal.state) HIPCHK(c, hipMalloc((void **)&c->kal.state, (size_t)c->cfg.n_streams * sizeof(KalmanState)));
+    c->kal.dt = dt; c->kal.sig_accel = sigma_accel; c->kal.sig_noise = sigma_noise;
+    c->kal.threshold = (int)(timeout / dt);                     // KalmanFilter2D.cpp:74-76
+    launch_kalman_reset(c->kal.state, c->cfg.n_streams, c->kal_ticket, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->kal_on = true;
+    return OATGPU_OK;
+}
+
 extern "C" int oatgpu_set_roi_mask(oatgpu_ctx *c, int32_t s, const uint8_t *roi_mask)
 {
     int rc = check_stream_ix(c, s);
@@ -552,6 +579,15 @@ static void to_position(const ResultRec &r, oatgpu_position *o)
     o->y = m01 / m00;
     o->area = m00;
     o->a00 = r.a00; o->a10 = r.a10; o->a01 = r.a01;
+    o->raw_valid = 1; o->raw_x = o->x; o->raw_y = o->y;
+}
+
+// posifilt kalman's view of the token (KalmanFilter2D.cpp:123-137): position/velocity = predicted state
+static void apply_kalman(const ResultRec &r, oatgpu_position *o)
+{
+    o->valid = r.kal_valid;
+    o->velocity_valid = r.kal_valid;
+    o->x = r.kx; o->y = r.ky; o->vx = r.kvx; o->vy = r.kvy;
 }
 
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
@@ -743,6 +779,13 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
         int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, ps ? ps->e[3] : nullptr);
         if (rc) return rc;
     }
+    if (c->kal_on) {
+        KalmanLaunch kl = c->kal;
+        kl.ticket = c->kal_ticket++;
+        launch_kalman(kl, c->res_dev + (size_t)slot * n, n, B);
+        HIPCHK(c, hipGetLastError());
+    }
+    c->slot_filtered[slot] = c->kal_on;
     if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
     c->last_q = k;
@@ -758,7 +801,10 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
     HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
-    for (int s = 0; s < c->cfg.n_streams; ++s) to_position(r[s], &out[s]);
+    for (int s = 0; s < c->cfg.n_streams; ++s) {
+        to_position(r[s], &out[s]);
+        if (c->slot_filtered[slot]) apply_kalman(r[s], &out[s]);
+    }
     c->col_total++;
     c->ring_count--;
     return OATGPU_OK;

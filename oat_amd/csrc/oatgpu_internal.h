@@ -158,7 +158,28 @@ struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
     int first_pixel;
     int valid;
+    // written by k_kalman when the position filter is on
+    int kal_valid;
+    int pad_;
+    double kx, ky, kvx, kvy;
 };
+
+// `posifilt kalman` state of one camera stream (KalmanFilter2D.h:53-82 + cv::KalmanFilter members)
+struct KalmanState {
+    double statePre[4], statePost[4], Ppre[16], Ppost[16];
+    double meas[2];          // kf_meas_ (keeps the stale measurement across missed detections)
+    double reported[4];      // kf_predicted_state_ before it starts sharing statePre's buffer
+    int found, missing, aliased;
+    unsigned ticket;         // index of the next frame allowed to update this filter
+};
+struct KalmanLaunch {
+    KalmanState *state;      // [n_streams]
+    double dt, sig_accel, sig_noise;
+    int threshold;           // not_found_count_threshold_ = (int)(timeout / dt)
+    unsigned ticket;         // this frame's index
+};
+void launch_kalman(const KalmanLaunch &k, ResultRec *results, int n_streams, hipStream_t st);
+void launch_kalman_reset(KalmanState *state, int n_streams, unsigned ticket, hipStream_t st);
 
 void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode, int first_stream,
                   int n_streams, hipStream_t st);

@@ -33,7 +33,9 @@ class Config(C.Structure):
 
 class Position(C.Structure):
     _fields_ = [("valid", C.c_int32), ("first_pixel", C.c_int32), ("x", C.c_double), ("y", C.c_double),
-                ("area", C.c_double), ("a00", C.c_int64), ("a10", C.c_int64), ("a01", C.c_int64)]
+                ("area", C.c_double), ("a00", C.c_int64), ("a10", C.c_int64), ("a01", C.c_int64),
+                ("velocity_valid", C.c_int32), ("raw_valid", C.c_int32), ("vx", C.c_double), ("vy", C.c_double),
+                ("raw_x", C.c_double), ("raw_y", C.c_double)]
 
 
 class Profile(C.Structure):
@@ -64,6 +66,7 @@ SIGNATURES = {
     "oatgpu_get_stream": (C.c_void_p, [_ctx]),
     "oatgpu_synchronize": (C.c_int, [_ctx]),
     "oatgpu_set_detector": (C.c_int, [_ctx] + [C.c_int32] * 8 + [C.c_double, C.c_double]),
+    "oatgpu_set_kalman": (C.c_int, [_ctx, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     "oatgpu_set_roi_mask": (C.c_int, [_ctx, C.c_int32, _u8p]),
     "oatgpu_bsub_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_thresh_filter": (C.c_int, [_ctx, _u8p, _u8p, C.c_int32, C.c_int32]),

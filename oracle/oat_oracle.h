@@ -202,6 +202,29 @@ void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double lear
                     const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
                     oat_detection *out, int nthreads);
 
+/* ------------------------------------------------- posifilt kalman -------- */
+
+/* `oat posifilt kalman` (src/positionfilter/KalmanFilter2D.cpp:95-210): constant-velocity
+ * 4-state filter per position stream; see kalman.c for the restated quirks. */
+typedef struct {
+    double dt;            /* 0.02  --dt                         */
+    double timeout;       /* 0     --timeout, seconds           */
+    double sigma_accel;   /* 5.0   --sigma-accel                */
+    double sigma_noise;   /* 0.0   --sigma-noise                */
+} oat_kalman_params;
+
+typedef struct {
+    int position_valid, velocity_valid;
+    double x, y, vx, vy;
+} oat_kalman_out;
+
+typedef struct oat_kalman oat_kalman;
+void oat_kalman_default_params(oat_kalman_params *p);
+oat_kalman *oat_kalman_create(const oat_kalman_params *p);
+void oat_kalman_destroy(oat_kalman *k);
+/* KalmanFilter2D::filter(position): in = posidet's (position_valid, position) */
+void oat_kalman_filter(oat_kalman *k, int position_valid, double x, double y, oat_kalman_out *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,50 @@ def mog2_pixel_trace(pixels, rates, nmix=5):
     return out
 
 
+def kalman_trace(samples, dt=0.02, timeout=0.0, sigma_accel=5.0, sigma_noise=0.0):
+    """Independent float64 restatement of `posifilt kalman` (KalmanFilter2D.cpp:95-210 over
+    cv::KalmanFilter(4,2,0,CV_64F)) with numpy matrix algebra and np.linalg.solve -- a different
+    evaluation order from oracle/kalman.c on purpose: the two must agree to rounding, not bit for bit.
+    samples: list of (valid, x, y).  Returns per sample [valid, x, y, vx, vy]."""
+    A = np.eye(4); Q = np.eye(4); R = np.eye(2); H = np.zeros((2, 4))      # KalmanFilter::init
+    x_pre = np.zeros(4); x_post = np.zeros(4); P_pre = np.zeros((4, 4)); P_post = np.zeros((4, 4))
+    reported = np.full(4, 6.0)          # Mat_<double>{4, 1, CV_64F}: filled with 6.0
+    meas = np.full(2, 6.0)
+    aliased = False
+    found, missing = False, 0
+    threshold = int(timeout / dt)
+    out = []
+    for valid, mx, my in samples:
+        if valid:
+            meas = np.array([mx, my], float)
+            missing = 0
+            if not found:
+                A = np.eye(4); A[0, 1] = dt; A[2, 3] = dt
+                H = np.zeros((2, 4)); H[0, 0] = 1; H[1, 2] = 1
+                q = np.array([[dt ** 4 / 4, dt ** 3 / 2], [dt ** 3 / 2, dt ** 2]]) * sigma_accel ** 2
+                Q = np.zeros((4, 4)); Q[:2, :2] = q; Q[2:, 2:] = q
+                R = np.eye(2) * sigma_noise ** 2
+                P_pre = np.eye(4) * 1000.0
+                x_pre = np.array([mx, 0.0, my, 0.0]); x_post = x_pre.copy()
+            found = True
+        else:
+            missing += 1
+        if missing >= threshold:
+            found = False
+        if found:
+            x_pre = A @ x_post
+            P_pre = A @ P_post @ A.T + Q
+            x_post = x_pre.copy(); P_post = P_pre.copy()
+            aliased = True
+            S = H @ P_pre @ H.T + R
+            K = np.linalg.solve(S, H @ P_pre).T
+            x_post = x_pre + K @ (meas - H @ x_pre)
+            P_post = P_pre - K @ (H @ P_pre)
+        r = x_pre if aliased else reported
+        out.append([bool(found), float(r[0]), float(r[2]), float(r[1]), float(r[3])])
+    return out
+
+
 def main():
     rng = np.random.default_rng(20260929)
 
@@ -253,6 +297,25 @@ def main():
     pix = [cols[(t * 5 + t // 3) % 6] for t in range(40)]
     traces.append(dict(name="five_modes", rate=0.05, pixels=pix, frames=mog2_pixel_trace(pix, [0.05] * len(pix))))
     json.dump(traces, open(os.path.join(HERE, "mog2_trace.json"), "w"))
+    # ---- posifilt kalman traces ----
+    krng = np.random.default_rng(4242)
+    def walk(n, gaps=()):
+        xs = []
+        for t in range(n):
+            valid = not any(a <= t < b for a, b in gaps)
+            xs.append((valid, 300.0 + 4.0 * t + float(krng.normal(0, 1.5)), 200.0 - 2.5 * t + float(krng.normal(0, 1.5))))
+        return xs
+    ktr = []
+    for name, kw, samples in (
+            ("default_timeout0_never_tracks", {}, walk(12)),
+            ("timeout_100ms", dict(timeout=0.1), walk(40)),
+            ("short_gap_uses_stale_measurement", dict(timeout=0.1), walk(40, gaps=((10, 13),))),
+            ("long_gap_reinitialises", dict(timeout=0.1, sigma_noise=2.0), walk(60, gaps=((15, 30), (45, 47)))),
+            ("starts_invalid", dict(timeout=0.2, sigma_accel=50.0, sigma_noise=1.0, dt=0.01), walk(50, gaps=((0, 6),))),
+    ):
+        ktr.append(dict(name=name, params=kw, samples=[[bool(v), x, y] for v, x, y in samples],
+                        out=kalman_trace(samples, **kw)))
+    json.dump(ktr, open(os.path.join(HERE, "kalman_trace.json"), "w"))
     print("wrote golden vectors to", HERE)
 
 

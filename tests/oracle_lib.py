@@ -313,3 +313,36 @@ def thresh_filter(frame, i_min, i_max):
     ch = 3 if f.ndim == 3 else 1
     lib.oat_thresh_filter(_p(f), f.size // ch, ch, int(i_min), int(i_max))
     return f
+
+
+class KalmanParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("timeout", C.c_double), ("sigma_accel", C.c_double),
+                ("sigma_noise", C.c_double)]
+
+
+class KalmanOut(C.Structure):
+    _fields_ = [("position_valid", C.c_int), ("velocity_valid", C.c_int), ("x", C.c_double), ("y", C.c_double),
+                ("vx", C.c_double), ("vy", C.c_double)]
+
+
+class Kalman:
+    """posifilt kalman oracle (KalmanFilter2D.cpp:95-210)."""
+
+    def __init__(self, dt=0.02, timeout=0.0, sigma_accel=5.0, sigma_noise=0.0):
+        lib.oat_kalman_create.restype = C.c_void_p
+        lib.oat_kalman_create.argtypes = [C.POINTER(KalmanParams)]
+        lib.oat_kalman_destroy.argtypes = [C.c_void_p]
+        lib.oat_kalman_filter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(KalmanOut)]
+        p = KalmanParams(dt, timeout, sigma_accel, sigma_noise)
+        self.h = lib.oat_kalman_create(C.byref(p))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.oat_kalman_destroy(self.h)
+            self.h = None
+
+    def filter(self, valid, x, y):
+        o = KalmanOut()
+        lib.oat_kalman_filter(self.h, int(bool(valid)), float(x), float(y), C.byref(o))
+        return dict(position_valid=bool(o.position_valid), velocity_valid=bool(o.velocity_valid), x=o.x, y=o.y,
+                    vx=o.vx, vy=o.vy)

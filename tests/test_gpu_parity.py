@@ -739,3 +739,83 @@ def test_error_behaviour(A):
     d = A.HSVDetector(10, 10)
     with pytest.raises(A.OatGpuError):
         d.detectPosition(np.zeros((10, 10, 3), np.uint8), stream=3)
+
+
+# ------------------------------------------------------- posifilt kalman ----
+
+def _kalman_frames(rows, cols, n, nframes, gaps):
+    """Per stream one bright square on a straight path; no square during the gaps."""
+    out = []
+    for t in range(nframes):
+        f = np.zeros((n, rows, cols, 3), np.uint8)
+        for s in range(n):
+            if any(a <= t < b for a, b in gaps[s]):
+                continue
+            x = 10 + (3 + s) * t % (cols - 30)
+            y = 8 + (2 * t + 5 * s) % (rows - 24)
+            f[s, y:y + 9 + s, x:x + 12] = 255
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_kalman_filter_on_the_batch_matches_oracle(A, pipelined):
+    """oatgpu_set_kalman: detections of every stream filtered on the device, in frame order even
+    though consecutive frames use different HIP streams; equal (bit for bit) to the oracle filter
+    fed with the oracle detections."""
+    import torch
+    rows, cols, n, nframes = 96, 160, 3, 60
+    gaps = [((20, 23),), ((0, 4), (30, 45)), ()]
+    frames = _kalman_frames(rows, cols, n, nframes, gaps)
+    kw = dict(dt=0.01, timeout=0.08, sigma_accel=30.0, sigma_noise=1.5)
+    hp = A.HotPath(rows, cols, n_streams=n, ring_depth=4, adaptation_coeff=0.0, erode=0, dilate=3,
+                   v_thresh=(200, 256), area=(4.0, 1e6))
+    hp.set_kalman(True, **kw)
+    p = O.hsv_params(v_lo=200, v_hi=256, erode=0, dilate=3, min_area=4.0, max_area=1e6)
+    orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    kal = [O.Kalman(**kw) for _ in range(n)]
+    want = []
+    for f in frames:
+        row = []
+        for s in range(n):
+            d, _ = O.chain_step(orc[s], f[s], 0.0, p)
+            row.append((d, kal[s].filter(d["valid"], d["x"], d["y"])))
+        want.append(row)
+
+    got = []
+    if pipelined:
+        dev = torch.device("cuda:0")
+        bufs = [torch.from_numpy(f).to(dev) for f in frames]
+        torch.cuda.synchronize()
+        for t in range(nframes):
+            if hp.outstanding() == 4:
+                got.append(hp.collect())
+            hp.enqueue_dev(bufs[t].data_ptr())
+        while hp.outstanding():
+            got.append(hp.collect())
+    else:
+        got = [hp.track(list(f)) for f in frames]
+
+    tracked = 0
+    for t in range(nframes):
+        for s in range(n):
+            g, (d, k) = got[t][s], want[t][s]
+            assert g.raw_valid == d["valid"], (t, s)
+            if d["valid"]:
+                assert (g.raw_x, g.raw_y, g.a00) == (d["x"], d["y"], d["a00"]), (t, s)
+            assert g.position_valid == k["position_valid"] and g.velocity_valid == k["velocity_valid"], (t, s)
+            assert (g.x, g.y, g.vx, g.vy) == (k["x"], k["y"], k["vx"], k["vy"]), (t, s, g, k)
+            tracked += g.position_valid
+    assert tracked > 100
+    # stream 1 sees nothing for 15 frames: the filter coasts 8 frames on the stale measurement, then drops
+    assert [got[t][1].position_valid for t in range(29, 46)] == [True] * 8 + [False] * 8 + [True]
+
+    # the reference's defaults (--timeout 0) never track; turning the filter off restores raw output
+    hp.set_kalman(True)
+    r = hp.track(list(frames[10]))
+    assert all((not q.position_valid) and (q.x, q.y, q.vx, q.vy) == (6.0, 6.0, 6.0, 6.0) and q.raw_valid for q in r)
+    hp.set_kalman(False)
+    r = hp.track(list(frames[11]))
+    assert all(q.position_valid and not q.velocity_valid and (q.x, q.y) == (q.raw_x, q.raw_y) for q in r)
+    with pytest.raises(A.OatGpuError):
+        hp.set_kalman(True, dt=0.0)

@@ -151,3 +151,31 @@ def test_model_file_resumes_across_process_restarts(host_bins, tmp_path, fused):
             hits += 1
             assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, t
     assert hits >= n - 3
+
+
+@pytest.mark.gpu
+def test_fused_tracker_with_kalman_matches_oracle(host_bins, tmp_path):
+    """oat-track-hip --kalman = frameserve -> mog -> col -> posidet hsv -> posifilt kalman in one process."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 30
+    st = SyntheticStream(rows, cols, 9, n_discs=1)
+    frames = [st.frame(t, with_discs=(t > 0 and not 12 <= t < 15)) for t in range(n)]
+    got = _run_pipeline(host_bins, tmp_path, frames, True,
+                        ["--kalman", "--dt", "0.005", "-T", "0.05", "--sigma-accel", "40", "-n", "1.0"])
+    assert len(got) == n
+    orc = O.Mog2(rows, cols, 3)
+    kal = O.Kalman(dt=0.005, timeout=0.05, sigma_accel=40.0, sigma_noise=1.0)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    tracked = 0
+    for t, (f, g) in enumerate(zip(frames, got)):
+        d, _ = O.chain_step(orc, f, 0.01, p)
+        k = kal.filter(d["valid"], d["x"], d["y"])
+        assert g["pos_ok"] == k["position_valid"] and g["vel_ok"] == k["velocity_valid"], t
+        if k["position_valid"]:
+            tracked += 1
+            assert abs(g["pos_xy"][0] - k["x"]) < 1e-4 and abs(g["pos_xy"][1] - k["y"]) < 1e-4, t
+            assert abs(g["vel_xy"][0] - k["vx"]) < 1e-4 * max(1, abs(k["vx"])), t
+            assert abs(g["vel_xy"][1] - k["vy"]) < 1e-4 * max(1, abs(k["vy"])), t
+    assert tracked >= n - 4

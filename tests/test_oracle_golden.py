@@ -193,3 +193,36 @@ def test_grey_conversion_and_sibling_filters_known_answers():
     assert b.filter(np.array([[10]], np.uint8)).tolist() == [[0]]
     assert b.filter(np.array([[21]], np.uint8)).tolist() == [[21 - 16]]
     assert b.filter(np.array([[21]], np.uint8)).tolist() == [[21 - 18]]      # 0.5*21 + 0.5*15.5 = 18.25 -> 18
+
+
+def test_kalman_traces_against_independent_numpy_restatement(golden_dir):
+    """oracle/kalman.c vs tests/golden/kalman_trace.json (numpy matrix algebra + linalg.solve):
+    flags identical, values equal to rounding (the two use different evaluation orders)."""
+    for tr in json.load(open(os.path.join(golden_dir, "kalman_trace.json"))):
+        k = O.Kalman(**tr["params"])
+        for t, ((v, x, y), w) in enumerate(zip(tr["samples"], tr["out"])):
+            o = k.filter(v, x, y)
+            assert o["position_valid"] == o["velocity_valid"] == w[0], (tr["name"], t)
+            for got, want in zip((o["x"], o["y"], o["vx"], o["vy"]), w[1:]):
+                assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (tr["name"], t, got, want)
+
+
+def test_kalman_reference_quirks():
+    """The observable oddities of KalmanFilter2D.cpp a drop-in has to keep."""
+    k = O.Kalman()                                   # default --timeout 0: threshold 0, never tracks
+    for t in range(5):
+        o = k.filter(True, 10.0 + t, 20.0)
+        assert not o["position_valid"] and (o["x"], o["y"], o["vx"], o["vy"]) == (6.0, 6.0, 6.0, 6.0)
+    k = O.Kalman(timeout=0.1)                        # threshold 5
+    o = k.filter(False, 0, 0)                        # nothing seen yet
+    assert not o["position_valid"] and o["x"] == 6.0
+    o = k.filter(True, 100.0, 50.0)                  # first detection: predicted state = the measurement
+    assert o["position_valid"] and (o["x"], o["y"], o["vx"], o["vy"]) == (100.0, 50.0, 0.0, 0.0)
+    o = k.filter(True, 102.0, 50.0)                  # sigma_noise 0: the correction trusted the measurement fully
+    assert o["x"] == 100.0 and o["vx"] == 0.0        # ... but the report is the PREDICTION made before it
+    o = k.filter(True, 104.0, 50.0)                  # P' = Q on the first step => velocity gain 2/dt: v = 2 px * 100 /s
+    assert abs(o["vx"] - 200.0) < 1e-9 and abs(o["x"] - 106.0) < 1e-9 and o["vy"] == 0.0
+    seen = [k.filter(False, 0, 0)["position_valid"] for _ in range(6)]
+    assert seen == [True, True, True, True, False, False]       # 5th miss reaches the threshold
+    o = k.filter(True, 300.0, 10.0)                  # re-initialised at the new measurement
+    assert o["position_valid"] and (o["x"], o["y"], o["vx"], o["vy"]) == (300.0, 10.0, 0.0, 0.0)
