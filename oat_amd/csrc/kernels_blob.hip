@@ -543,8 +543,8 @@ __global__ __launch_bounds__(256) void k_green_select(Geom g, BlobBuffers b, dou
     }
     if (threadIdx.x == 0) {
         const u64 key = red[0];
-        ResultRec r;
-        r.a00 = r.a10 = r.a01 = 0; r.first_pixel = -1; r.valid = 0;
+        ResultRec r{};
+        r.first_pixel = -1;
         if (key) {
             const int h = (int)(key & 0xffffffffull);
             r.a00 = __hip_atomic_load(&acc[(size_t)h * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -278,7 +278,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         c->back_graph.assign(c->ring_slots, nullptr);
         c->slot_filtered.assign(c->ring_slots, 0);
         for (auto &e : c->ring_ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming | ((c->expt & 8) ? hipEventDisableSystemFence : 0)) != hipSuccess) ok = false;
     }
     // the model's mode counters start at zero; everything else is written before it is read
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;

@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -215,6 +216,78 @@ protected:
 struct Options {
     std::vector<std::string> positional;
     std::map<std::string, std::string> kv;
+    std::string config_file, config_key;      // -c FILE KEY (Configurable.h:46-49)
+
+    // `-c FILE KEY`: table [KEY] of a TOML file supplies options the command line did not
+    // (TOMLSanitize.h:73-98 getConfigTable, :102-118 checkKeys, :169-196 getValue -- the command
+    // line wins).  The reader covers the TOML the reference's configurations use: comments,
+    // [table] headers, `key = value` with numbers, booleans, quoted strings and (possibly
+    // multi-line) arrays of those; array values are handed on as their literal text, which is what
+    // arr2() parses.
+    void apply_config(const std::vector<std::string> &valid_keys, const std::vector<std::string> &flags = {})
+    {
+        if (config_file.empty()) return;
+        std::ifstream in(config_file);
+        if (!in) throw std::runtime_error("Could not open configuration file '" + config_file + "'.");
+        auto trim = [](std::string t) {
+            const size_t a = t.find_first_not_of(" \t\r\n"), b = t.find_last_not_of(" \t\r\n");
+            return a == std::string::npos ? std::string() : t.substr(a, b - a + 1);
+        };
+        auto strip_comment = [](const std::string &l) {
+            char q = 0;
+            for (size_t i = 0; i < l.size(); ++i) {
+                if (q) { if (l[i] == q) q = 0; }
+                else if (l[i] == '"' || l[i] == '\'') q = l[i];
+                else if (l[i] == '#') return l.substr(0, i);
+            }
+            return l;
+        };
+        std::string line, table;
+        bool found = false;
+        int lineno = 0;
+        while (std::getline(in, line)) {
+            ++lineno;
+            line = trim(strip_comment(line));
+            if (line.empty()) continue;
+            if (line.front() == '[' && line.find('=') == std::string::npos) {
+                if (line.back() != ']') throw std::runtime_error(config_file + ":" + std::to_string(lineno) + ": malformed table header");
+                table = trim(line.substr(1, line.size() - 2));
+                if (table == config_key) found = true;
+                continue;
+            }
+            const size_t eq = line.find('=');
+            if (eq == std::string::npos) throw std::runtime_error(config_file + ":" + std::to_string(lineno) + ": expected key = value");
+            std::string key = trim(line.substr(0, eq)), val = trim(line.substr(eq + 1));
+            if (key.size() > 1 && (key.front() == '"' || key.front() == '\'')) key = key.substr(1, key.size() - 2);
+            auto depth = [](const std::string &v) {
+                int d = 0; char q = 0;
+                for (char ch : v) {
+                    if (q) { if (ch == q) q = 0; }
+                    else if (ch == '"' || ch == '\'') q = ch;
+                    else if (ch == '[') ++d;
+                    else if (ch == ']') --d;
+                }
+                return d;
+            };
+            while (depth(val) > 0 && std::getline(in, line)) { ++lineno; val += " " + trim(strip_comment(line)); }
+            if (val.empty() || depth(val) != 0) throw std::runtime_error(config_file + ":" + std::to_string(lineno) + ": malformed value for '" + key + "'");
+            if (table != config_key) continue;
+            bool known = false;
+            for (auto &k : valid_keys) if (k == key) known = true;
+            if (!known) throw std::runtime_error("Unknown configuration key '" + key + "'.");      // TOMLSanitize.h:114
+            if (kv.count(key)) continue;                                                           // command line wins
+            bool is_flag = false;
+            for (auto &f : flags) if (f == key) is_flag = true;
+            if (is_flag) {
+                if (val == "true") kv[key] = "true";
+                else if (val != "false") throw std::runtime_error("'" + key + "' must be a TOML value of type bool.");
+                continue;
+            }
+            if (val.size() > 1 && (val.front() == '"' || val.front() == '\'')) val = val.substr(1, val.size() - 2);
+            kv[key] = val;
+        }
+        if (!found) throw std::runtime_error("No configuration table named '" + config_key + "' was provided in the configuration file '" + config_file + "'.");
+    }
 
     static Options parse(int argc, char **argv, const std::map<std::string, std::string> &short2long,
                          const std::vector<std::string> &flags = {})
@@ -225,11 +298,19 @@ struct Options {
             bool is_num = a.size() > 1 && a[0] == '-' && (isdigit((unsigned char)a[1]) || a[1] == '.');
             if (a.size() > 1 && a[0] == '-' && !is_num) {
                 std::string key;
-                if (a[1] == '-') key = a.substr(2);
+                if (a == "-c") key = "config";
+                else if (a[1] == '-') key = a.substr(2);
                 else {
                     auto it = short2long.find(a.substr(1));
                     if (it == short2long.end()) throw std::runtime_error("unrecognised option '" + a + "'");
                     key = it->second;
+                }
+                if (key == "config") {                                // multitoken: FILE KEY
+                    if (i + 2 >= argc || argv[i + 1][0] == '-' || argv[i + 2][0] == '-')
+                        throw std::runtime_error("Configuration must be supplied as file key pair.");   // TOMLSanitize.h:82
+                    o.config_file = argv[++i];
+                    o.config_key = argv[++i];
+                    continue;
                 }
                 bool is_flag = false;
                 for (auto &f : flags) if (f == key) is_flag = true;

@@ -145,9 +145,16 @@ static void usage()
 int main(int argc, char **argv)
 {
     try {
-        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"I", "intensity"}, {"h", "help"}}, {"help"});
+        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"I", "intensity"}, {"h", "help"}, {"v", "version"}}, {"help", "version"});
+        if (o.has("version")) { std::cout << "oat-framefilt-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
         const std::string type = o.positional[0];
+        // option names per TYPE: BackgroundSubtractorMOG.cpp:51-67, ColorConvert.cpp:45-63,
+        // BackgroundSubtractor.cpp:42-60, Threshold.cpp:40-54
+        if (type == "mog") o.apply_config({"adaptation-coeff", "gpu-index", "model-file"});
+        else if (type == "col") o.apply_config({"color"});
+        else if (type == "bsub") o.apply_config({"adaptation-coeff", "background"});
+        else if (type == "thresh") o.apply_config({"intensity"});
         std::unique_ptr<Component> comp;
         if (type == "mog") {
             auto f = std::make_unique<BackgroundSubtractorMOG>(o.positional[1], o.positional[2]);

@@ -61,11 +61,16 @@ int main(int argc, char **argv)
         const bool is_diff = argc > 1 && std::string(argv[1]) == "diff";
         Options o = Options::parse(argc, argv,
             {{"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"T", "thresh"}, {"e", "erode"},
-             {"d", is_diff ? "diff-threshold" : "dilate"}, {"b", "blur"}, {"a", "area"}, {"t", "tune"}, {"h", "help"}},
-            {"help", "tune"});
+             {"d", is_diff ? "diff-threshold" : "dilate"}, {"b", "blur"}, {"a", "area"}, {"t", "tune"}, {"h", "help"}, {"v", "version"}},
+            {"help", "version", "tune"});
+        if (o.has("version")) { std::cout << "oat-posidet-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
         const std::string type = o.positional[0];
         if (type != "hsv" && type != "thresh" && type != "diff") throw std::runtime_error("Selected TYPE is invalid.");
+        // option names per TYPE: HSVDetector.cpp:49-75, SimpleThreshold.cpp:49-69, DifferenceDetector.cpp:41-62
+        if (type == "hsv") o.apply_config({"h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "tune"}, {"tune"});
+        else if (type == "thresh") o.apply_config({"thresh", "erode", "dilate", "area", "tune"}, {"tune"});
+        else o.apply_config({"diff-threshold", "blur", "area", "tune"}, {"tune"});
         if (o.has("tune")) throw std::runtime_error("--tune needs a GUI and is not available in the hip detector");
         auto d = std::make_unique<GpuDetector>(o.positional[1], o.positional[2],
                                                type == "hsv" ? Kind::HSV : type == "thresh" ? Kind::THRESH : Kind::DIFF);

@@ -63,12 +63,15 @@ int main(int argc, char **argv)
     try {
         Options o = Options::parse(argc, argv,
             {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
-             {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"h", "help"}}, {"help", "kalman"});
+             {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"h", "help"}, {"v", "version"}}, {"help", "version", "kalman"});
+        if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE SINK [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]] [--model-file FILE]\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n";
             return o.has("help") ? 0 : -1;
         }
+        o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise"}, {"kalman"});
         auto t = std::make_unique<FusedTracker>(o.positional[0], o.positional[1]);
         t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
         double a, b;

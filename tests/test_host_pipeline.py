@@ -67,13 +67,15 @@ def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
     subprocess.run([os.path.join(host_bins, "oat-clean-hip"), addr], capture_output=True)
 
 
-def _run_pipeline(host_bins, tmp_path, frames, fused, mog_args=()):
+def _run_pipeline(host_bins, tmp_path, frames, fused, mog_args=(), config=None):
     rows, cols = frames[0].shape[:2]
     raw = tmp_path / "frames.raw"
     np.stack(frames).tofile(raw)
     tag = "oat_t_" + uuid.uuid4().hex[:8]
     a_raw, a_filt, a_hsv, a_pos = (tag + s for s in ("raw", "filt", "hsv", "pos"))
     det = ["-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7"]
+    if config:                       # the same options from table [KEY] of a TOML file (-c FILE KEY)
+        det = ["-c", str(config[0]), config[1]]
     procs = []
     B = lambda n: os.path.join(host_bins, n)
     reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
@@ -153,16 +155,52 @@ def test_model_file_resumes_across_process_restarts(host_bins, tmp_path, fused):
     assert hits >= n - 3
 
 
+def test_config_file_errors_are_the_references(host_bins, tmp_path):
+    """-c FILE KEY (TOMLSanitize.h:73-118): bad pair, missing table, unknown key -> error exit, the
+    reference's messages; none of this needs a GPU (options are parsed before any device work)."""
+    toml = tmp_path / "c.toml"
+    toml.write_text("[good]\nerode = 3 # comment\nh-thresh = [100,\n 125]\n[bad]\nnokey = 1\n")
+    exe = os.path.join(host_bins, "oat-posidet-hip")
+    for args, msg in ((["-c", str(toml)], "Configuration must be supplied as file key pair."),
+                      (["-c", str(toml), "nope"], "No configuration table named 'nope'"),
+                      (["-c", str(toml), "bad"], "Unknown configuration key 'nokey'."),
+                      (["-c", str(tmp_path / "absent.toml"), "good"], "Could not open configuration file")):
+        r = subprocess.run([exe, "hsv", "x_src", "x_snk"] + args, capture_output=True, text=True, timeout=30)
+        assert r.returncode == 255 and msg in r.stderr, (args, r.stderr)
+
+
 @pytest.mark.gpu
-def test_fused_tracker_with_kalman_matches_oracle(host_bins, tmp_path):
+@pytest.mark.parametrize("via_config", [False, True])
+def test_fused_tracker_with_kalman_matches_oracle(host_bins, tmp_path, via_config):
     """oat-track-hip --kalman = frameserve -> mog -> col -> posidet hsv -> posifilt kalman in one process."""
     import oracle_lib as O
     from oat_amd.synth import SyntheticStream
     rows, cols, n = 240, 320, 30
     st = SyntheticStream(rows, cols, 9, n_discs=1)
     frames = [st.frame(t, with_discs=(t > 0 and not 12 <= t < 15)) for t in range(n)]
-    got = _run_pipeline(host_bins, tmp_path, frames, True,
-                        ["--kalman", "--dt", "0.005", "-T", "0.05", "--sigma-accel", "40", "-n", "1.0"])
+    if via_config:
+        toml = tmp_path / "track.toml"
+        toml.write_text("""# everything oat-track-hip needs, from a configuration file
+[unrelated]
+erode = 11
+
+[tracker]
+h-thresh = [100, 125]     # blue disc
+s-thresh = [150, 256]
+v-thresh = [100,
+            256]
+erode = 3
+dilate = 7
+kalman = true
+dt = 0.005
+timeout = 0.05
+sigma-accel = 40.0
+sigma-noise = 1
+""")
+        got = _run_pipeline(host_bins, tmp_path, frames, True, config=(toml, "tracker"))
+    else:
+        got = _run_pipeline(host_bins, tmp_path, frames, True,
+                            ["--kalman", "--dt", "0.005", "-T", "0.05", "--sigma-accel", "40", "-n", "1.0"])
     assert len(got) == n
     orc = O.Mog2(rows, cols, 3)
     kal = O.Kalman(dt=0.005, timeout=0.05, sigma_accel=40.0, sigma_noise=1.0)
