@@ -170,8 +170,8 @@ def make_pool_device(rows, cols, ns, nframes, rank, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=48, help="distinct frame sets resident in HBM")
     ap.add_argument("--input", default="device", choices=["device", "host"],
