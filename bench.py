@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=48, help="distinct frame sets resident in HBM")
-    ap.add_argument("--input", default="device", choices=["device", "host"],
+    ap.add_argument("--input", default="device", choices=["device", "host", "host-sync"],
                     help="device: frames resident in HBM (the headline); host: pageable host frames through "
                          "oatgpu_track_batch, i.e. PCIe-inclusive (reported in DESIGN.md, never the headline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -230,11 +230,17 @@ def main():
     raw_results = []
 
     host_pool = None
-    if args.input == "host":
-        host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool[:8]]
+    if args.input in ("host", "host-sync"):
+        # PCIe-inclusive variants (never the headline value): "host" = page-locked frames through the
+        # pipelined oatgpu_track_enqueue (copies overlap compute), "host-sync" = pageable frames
+        # through the synchronous oatgpu_track_batch (what a one-frame-at-a-time caller gets)
+        if args.input == "host":
+            host_pool = [[f.numpy() for f in p.cpu().pin_memory()] for p in pool]
+        else:
+            host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool[:8]]
 
     def run(nsteps, keep=False):
-        if host_pool is not None:                      # synchronous host-buffer entry point
+        if host_pool is not None and args.input == "host-sync":
             for i in range(nsteps):
                 r = hp.track(host_pool[(i + 1) % len(host_pool)])
                 if keep:
@@ -247,7 +253,12 @@ def main():
         from oat_amd import ffi
         lib, ctx, lr = hp.lib, hp.ctx, hp.learning_coeff_
         enq, col = lib.oatgpu_track_enqueue_dev, lib.oatgpu_track_collect
-        ptrs = [C.c_void_p(p.data_ptr()) for p in pool]
+        if host_pool is not None:
+            enq_h = lib.oatgpu_track_enqueue
+            ptrs = [(ffi._u8p * ns)(*[ffi.u8(f) for f in fs]) for fs in host_pool]
+            enq = lambda ctx_, p_, lr_: enq_h(ctx_, p_, ns, lr_)
+        else:
+            ptrs = [C.c_void_p(p.data_ptr()) for p in pool]
         npool = len(ptrs)
         bufs = [(ffi.Position * ns)() for _ in range(nsteps)] if keep else [(ffi.Position * ns)()]
         outstanding = got = 0

@@ -223,6 +223,12 @@ int oatgpu_track_batch_dev(oatgpu_ctx *ctx, const void *frames_dev, double learn
  * order (exactly one result set per enqueued frame set, SURVEY.md 8b token
  * discipline).  Up to ring_depth enqueues may be outstanding. */
 int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate);
+/* Pipelined form for frames in HOST memory (what a camera or a shared-memory SOURCE hands over):
+ * the frames are copied to a per-slot device buffer on a copy stream of their own, so the copy of
+ * frame t+1 overlaps the kernels of frame t.  With page-locked frames (oatgpu_host_alloc /
+ * oatgpu_host_register) the copies are direct DMA; the caller must leave frames_host[i] untouched
+ * until the matching oatgpu_track_collect returns. */
+int oatgpu_track_enqueue(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n, double learning_rate);
 int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
 int oatgpu_track_outstanding(const oatgpu_ctx *ctx);
 

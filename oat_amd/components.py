@@ -289,11 +289,22 @@ class HotPath(_Context):
         self._chk(self.lib.oatgpu_track_batch_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_, self._pos))
         return self._out()
 
+    def enqueue(self, frames):
+        """Pipelined host-frame form (oatgpu_track_enqueue): frames must stay untouched until the
+        matching collect(); they are kept referenced here until then."""
+        fs = [_frame(f, self.frame_shape) for f in frames]
+        ptrs = (ffi._u8p * len(fs))(*[ffi.u8(f) for f in fs])
+        self._chk(self.lib.oatgpu_track_enqueue(self.ctx, ptrs, len(fs), self.learning_coeff_))
+        self._held = getattr(self, "_held", [])
+        self._held.append(fs)
+
     def enqueue_dev(self, dev_ptr):
         self._chk(self.lib.oatgpu_track_enqueue_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_))
 
     def collect(self):
         self._chk(self.lib.oatgpu_track_collect(self.ctx, self._pos))
+        if getattr(self, "_held", None):
+            self._held.pop(0)
         return self._out()
 
     def outstanding(self):

@@ -37,6 +37,9 @@ struct oatgpu_ctx {
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
+    hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
+    uint8_t *frames_ring = nullptr;  // [ring_slots][n_streams*rows*cols*channels] staging for host frames
+    std::vector<hipEvent_t> copy_ev; // [ring_slots] frames of this slot have arrived
     KalmanLaunch kal{};              // kal.state == nullptr: position filter off
     bool kal_on = false;
     unsigned kal_ticket = 0;         // ticket of the next enqueued frame
@@ -164,6 +167,9 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bsub_bg); hipFree(c->bsub_f); hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
     hipFree(c->kal.state);
+    hipFree(c->frames_ring);
+    for (auto e : c->copy_ev) hipEventDestroy(e);
+    if (c->stream_c) hipStreamDestroy(c->stream_c);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
@@ -708,7 +714,37 @@ static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
     return exec;
 }
 
+static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready);
+
 extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, double lr)
+{
+    return enqueue_frames(c, frames_dev, lr, nullptr);
+}
+
+extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_host, int32_t n, double lr)
+{
+    if (!c || !frames_host) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (n != c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "expected %d frames, got %d", c->cfg.n_streams, n);
+    if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
+    for (int s = 0; s < n; ++s) if (!frames_host[s]) return fail(c, OATGPU_E_INVALID, "null frame %d", s);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels, sb = fb * n;
+    if (!c->frames_ring) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+        HIPCHK(c, hipMalloc((void **)&c->frames_ring, sb * c->ring_slots));
+        c->copy_ev.resize(c->ring_slots);
+        for (auto &e : c->copy_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    // the slot's staging buffer was last read by the K1 of the frame collected from this slot
+    const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
+    uint8_t *dst = c->frames_ring + (size_t)slot * sb;
+    for (int s = 0; s < n; ++s)
+        HIPCHK(c, hipMemcpyAsync(dst + (size_t)s * fb, frames_host[s], fb, hipMemcpyHostToDevice, c->stream_c));
+    HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
+    return enqueue_frames(c, dst, lr, c->copy_ev[slot]);
+}
+
+static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready)
 {
     if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
@@ -735,6 +771,7 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
     // analysing earlier frames' masks.  It writes the threshold buffer of its own ring slot, whose
     // previous reader finished before that slot's result was collected: nothing to wait for.
+    if (frames_ready) HIPCHK(c, hipStreamWaitEvent(A, frames_ready, 0));
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
     // every camera stream advances one frame; launches are batched while the streams share a

@@ -819,3 +819,27 @@ def test_kalman_filter_on_the_batch_matches_oracle(A, pipelined):
     assert all(q.position_valid and not q.velocity_valid and (q.x, q.y) == (q.raw_x, q.raw_y) for q in r)
     with pytest.raises(A.OatGpuError):
         hp.set_kalman(True, dt=0.0)
+
+
+def test_pipelined_host_frames_equal_the_synchronous_call(A):
+    """oatgpu_track_enqueue (host frames, copy stream, per-slot staging) vs oatgpu_track_batch."""
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n, nframes = 120, 200, 2, 20
+    sts = [SyntheticStream(rows, cols, 40 + s, n_discs=1) for s in range(n)]
+    frames = [[st.frame(t, with_discs=t > 0) for st in sts] for t in range(nframes)]
+    kw = dict(n_streams=n, adaptation_coeff=0.02, erode=3, dilate=5, area=(10.0, 1e5), h_thresh=(100, 125),
+              s_thresh=(150, 256), v_thresh=(100, 256))
+    a = A.HotPath(rows, cols, ring_depth=3, **kw)
+    b = A.HotPath(rows, cols, **kw)
+    want = [b.track(f) for f in frames]
+    got = []
+    for f in frames:
+        if a.outstanding() == 3:
+            got.append(a.collect())
+        a.enqueue(f)
+    with pytest.raises(A.OatGpuError):
+        a.enqueue(frames[0][:1])                    # wrong number of frames
+    while a.outstanding():
+        got.append(a.collect())
+    assert got == want and sum(p.position_valid for r in got for p in r) >= 30
+    _same_state(a.mog_state(1), b.mog_state(1)[:4])
