@@ -161,6 +161,14 @@ static MogParams mogparams_of(const oatgpu_config &k)
     return m;
 }
 
+namespace {
+struct DevBuf {             // scoped device allocation
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+}  // namespace
+
 static void free_all(oatgpu_ctx *c)
 {
     if (!c) return;
@@ -905,11 +913,12 @@ extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_use
     if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures, mb = 4 * (size_t)c->cfg.channels;
-    uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_mu, npx));
-    HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * mb));
+    DevBuf b_mu, b_w, b_v, b_m;          // freed on every return path
+    HIPCHK(c, b_mu.alloc(npx));
+    HIPCHK(c, b_w.alloc(npx * k * 4));
+    HIPCHK(c, b_v.alloc(npx * k * 4));
+    HIPCHK(c, b_m.alloc(npx * k * mb));
+    uint8_t *d_mu = (uint8_t *)b_mu.p; float *d_w = (float *)b_w.p, *d_v = (float *)b_v.p, *d_m = (float *)b_m.p;
     launch_state_export(g, c->state + (size_t)s * mog_stream_floats(g.Palloc), c->nmodes + (size_t)s * g.Palloc, (int)k,
                         c->cfg.channels, d_mu, d_w, d_v, d_m, c->stream);
     hipError_t e = hipGetLastError();
@@ -918,7 +927,6 @@ extern "C" int oatgpu_mog_get_state(oatgpu_ctx *c, int32_t s, uint8_t *modes_use
     if (e == hipSuccess && variance) e = hipMemcpyAsync(variance, d_v, npx * k * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && mean) e = hipMemcpyAsync(mean, d_m, npx * k * mb, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_mu); hipFree(d_w); hipFree(d_v); hipFree(d_m);
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state export failed: %s", hipGetErrorString(e));
     if (nframes) *nframes = c->nframes[s];
     return OATGPU_OK;
@@ -936,11 +944,12 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W, k = c->cfg.nmixtures, mb = 4 * (size_t)c->cfg.channels;
-    uint8_t *d_mu = nullptr; float *d_w = nullptr, *d_v = nullptr, *d_m = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_mu, npx));
-    HIPCHK(c, hipMalloc((void **)&d_w, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_v, npx * k * 4));
-    HIPCHK(c, hipMalloc((void **)&d_m, npx * k * mb));
+    DevBuf b_mu, b_w, b_v, b_m;          // freed on every return path
+    HIPCHK(c, b_mu.alloc(npx));
+    HIPCHK(c, b_w.alloc(npx * k * 4));
+    HIPCHK(c, b_v.alloc(npx * k * 4));
+    HIPCHK(c, b_m.alloc(npx * k * mb));
+    uint8_t *d_mu = (uint8_t *)b_mu.p; float *d_w = (float *)b_w.p, *d_v = (float *)b_v.p, *d_m = (float *)b_m.p;
     hipError_t e = hipMemcpyAsync(d_mu, modes_used, npx, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_w, weight, npx * k * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_v, variance, npx * k * 4, hipMemcpyHostToDevice, c->stream);
@@ -951,7 +960,6 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_mu); hipFree(d_w); hipFree(d_v); hipFree(d_m);
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state import failed: %s", hipGetErrorString(e));
     c->nframes[s] = nframes;
     return OATGPU_OK;
