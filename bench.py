@@ -90,6 +90,25 @@ def parity_gate(wl, device, frames_seq):
     return "ok"
 
 
+def measured_run_gate(wl, frames_of_step, got_positions, nthreads):
+    """SURVEY.md 8d 'parity gates run with every benchmark': the positions the TIMED run itself
+    produced for stream 0, step by step, against the oracle chain run over the very same frame
+    sequence (model init, warm-up, timed steps).  frames_of_step: host frames of stream 0 in run
+    order; got_positions: (step index in that order, Position2D) pairs to compare."""
+    import oracle_lib as O
+    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+    p = oracle_params(wl)
+    want = [O.chain_step(orc, f, ALPHA, p, nthreads=nthreads)[0] for f in frames_of_step]
+    for t, g in got_positions:
+        w = want[t]
+        if g.position_valid != w["valid"]:
+            return f"valid mismatch at run frame {t}"
+        if w["valid"] and ((g.a00, g.a10, g.a01) != (w["a00"], w["a10"], w["a01"]) or
+                           abs(g.x - w["x"]) > 1e-4 or abs(g.y - w["y"]) > 1e-4):
+            return f"centroid mismatch at run frame {t}"
+    return "ok"
+
+
 def cpu_baseline(wl, frames_seq, budget_s=12.0):
     """The oracle (a port of the reference's CPU chain) timed on this host, bounded sample."""
     import oracle_lib as O
@@ -106,9 +125,19 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 2000:
             break
+    # (a) of SURVEY.md 8d: the same chain on ONE thread, a shorter sample
+    n1 = 0
+    t1 = time.perf_counter()
+    while True:
+        O.chain_step(orc, frames_seq[(n1 + 1) % len(frames_seq)], ALPHA, p, nthreads=1)
+        n1 += 1
+        el1 = time.perf_counter() - t1
+        if el1 >= budget_s / 4 or n1 >= 500:
+            break
     return dict(value=n / el, unit="frames/s", cores=ncores, kind="port",
                 sample=f"{n} frames of one {wl['cols']}x{wl['rows']} stream, {el:.1f} s, oracle chain "
-                       f"(MOG2, HSV, inRange, morphology rows over {ncores} threads; contour following 1 thread)")
+                       f"(MOG2, HSV, inRange, morphology rows over {ncores} threads; contour following 1 thread)",
+                value_1thread=n1 / el1, sample_1thread=f"{n1} frames, {el1:.1f} s, 1 thread")
 
 
 def make_pool_dense(rows, cols, ns, nframes, rank, dev):
@@ -185,7 +214,14 @@ def main():
                          "205 B/px) and a threshold window nothing passes; not a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--check-steps", type=int, default=64,
+                    help="timed steps of stream 0 replayed through the oracle after the run (0 = off)")
+    ap.add_argument("--learning-rate", type=float, default=None,
+                    help="MOG2 adaptation coefficient (default 0.01 = SURVEY 8d; 0 = Oat's default, frozen model)")
     args = ap.parse_args()
+    global ALPHA
+    if args.learning_rate is not None:
+        ALPHA = args.learning_rate
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -294,9 +330,20 @@ def main():
     # parity gate on this run's own frames -- after the timed region, with fresh
     # contexts, so that it cannot disturb the measurement
     parity = "skipped"
+    parity_detail = None
     if rank == 0 and not args.no_parity and not args.dense_model:
         parity = parity_gate(wl, local_rank, [p[0] for p in pool_host[:4]])
         log("parity gate:", parity)
+        if parity == "ok" and args.check_steps > 0:
+            # the timed run's own output: model init frame, W warm-up frames, then the first
+            # check_steps timed frames of stream 0, replayed through the oracle
+            G = min(args.check_steps, K)
+            s0 = [p[0].cpu().numpy() for p in pool]                  # stream 0 of every pool frame
+            order = [0] + [(i + 1) % len(pool) for i in range(W)] + [(i + 1) % len(pool) for i in range(G)]
+            parity = measured_run_gate(wl, [s0[i] for i in order], [(1 + W + i, positions[i][0]) for i in range(G)],
+                                       min(os.cpu_count() or 1, 32))
+            log(f"measured-run gate ({G} timed steps of stream 0 vs oracle):", parity)
+            parity_detail = f"fresh-context masks+centroids on 4 frames; first {G} timed steps of stream 0 vs the oracle: {parity}"
 
     # achievable HBM rates of this very device (plain streaming kernels), rank 0 only, after the timed region
     hbm_read = hbm_copy = None
@@ -377,6 +424,7 @@ def main():
         "positions_found": n_found,
         "positions_expected": total_streams * K,
         "parity": parity,
+        "parity_detail": parity_detail,
         "input": args.input,
         "dense_model": bool(args.dense_model),
     }

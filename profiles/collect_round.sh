@@ -26,6 +26,8 @@ for w in 1080p1 1080p16 4k1; do
   python $R/bench.py --workload $w --steps 2000 --warmup 200 2> $O/${TAG}_bench_$w.err | tail -1 > $O/${TAG}_bench_$w.json
 done
 python $R/bench.py --workload 4k1 --dense-model --pool 12 --steps 500 2>/dev/null | tail -1 > $O/${TAG}_bench_4k1_dense_model.json
+python $R/bench.py --workload 1080p1 --learning-rate 0 2>/dev/null | tail -1 > $O/${TAG}_bench_1080p1_alpha0.json     # Oat's default -a 0: frozen model
+python $R/bench.py --workload 4k1 --learning-rate 0 2>/dev/null | tail -1 > $O/${TAG}_bench_4k1_alpha0.json
 for w in 1080p1 4k1; do
   python $R/bench.py --workload $w --input host --steps 600 --warmup 100 2>/dev/null | tail -1 > $O/${TAG}_bench_${w}_host_input.json
   python $R/bench.py --workload $w --input host-sync --steps 400 --warmup 50 2>/dev/null | tail -1 > $O/${TAG}_bench_${w}_host_sync_input.json
