@@ -273,7 +273,7 @@ def main():
         if args.input == "host":
             host_pool = [[f.numpy() for f in p.cpu().pin_memory()] for p in pool]
         else:
-            host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool[:8]]
+            host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool]
 
     def run(nsteps, keep=False):
         if host_pool is not None and args.input == "host-sync":
