@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +31,8 @@ struct oatgpu_ctx {
     Geom g;
     hipStream_t stream = nullptr;   // stream A: uploads + the fused per-pixel kernel
     bool own_stream = false;
+    bool private_streams = false;   // OATGPU_PRIVATE_STREAMS: streams of its own instead of the device's shared ones
+    bool have_shared = false;
     static constexpr int kNB = 4;
     int nb = 2;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
     hipStream_t stream_b[kNB] = {}; // streams B0/B1: morphology + blob analysis of even/odd frames,
@@ -161,6 +165,58 @@ static MogParams mogparams_of(const oatgpu_config &k)
     return m;
 }
 
+// The HIP streams are shared by all contexts of a device in this process.  Measured on MI355X /
+// ROCm 7.2: with five or more ACTIVE HIP streams in one process every kernel -- K1 included -- runs
+// 2-4x slower (two contexts with private streams: 18.9k fps together, against 38.3k fps for one context
+// with both cameras), whatever GPU_MAX_HW_QUEUES says.  With one A and kNB B streams per device the
+// process stays at three (four with the host-frame copy stream) however many contexts it holds;
+// contexts then serialise on them, which costs nothing because each of their kernels fills the GPU.
+namespace {
+struct DeviceStreams {
+    int refs = 0;
+    hipStream_t a = nullptr, b[oatgpu_ctx::kNB] = {}, copy = nullptr;
+};
+std::mutex g_streams_mutex;
+std::map<int, DeviceStreams> g_streams;      // by device ordinal
+
+bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
+{
+    std::lock_guard<std::mutex> lk(g_streams_mutex);
+    DeviceStreams &d = g_streams[device];
+    bool ok = true;
+    if (!d.a) ok = hipStreamCreateWithFlags(&d.a, hipStreamNonBlocking) == hipSuccess;
+    // the B streams carry short latency-bound kernels that must slip in between the big
+    // bandwidth-bound launches of stream A: highest priority
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    for (int q = 0; q < nb && ok; ++q)
+        if (!d.b[q]) ok = hipStreamCreateWithPriority(&d.b[q], hipStreamNonBlocking, greatest) == hipSuccess;
+    if (!ok) return false;
+    d.refs++;
+    *a = d.a;
+    for (int q = 0; q < nb; ++q) b[q] = d.b[q];
+    return true;
+}
+hipStream_t acquire_copy_stream(int device)
+{
+    std::lock_guard<std::mutex> lk(g_streams_mutex);
+    DeviceStreams &d = g_streams[device];
+    if (!d.copy && hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking) != hipSuccess) d.copy = nullptr;
+    return d.copy;
+}
+void release_streams(int device)
+{
+    std::lock_guard<std::mutex> lk(g_streams_mutex);
+    auto it = g_streams.find(device);
+    if (it == g_streams.end() || --it->second.refs > 0) return;
+    DeviceStreams &d = it->second;
+    if (d.a) hipStreamDestroy(d.a);
+    for (auto sb : d.b) if (sb) hipStreamDestroy(sb);
+    if (d.copy) hipStreamDestroy(d.copy);
+    g_streams.erase(it);
+}
+}  // namespace
+
 namespace {
 struct DevBuf {             // scoped device allocation
     void *p = nullptr;
@@ -177,7 +233,6 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->kal.state);
     hipFree(c->frames_ring);
     for (auto e : c->copy_ev) hipEventDestroy(e);
-    if (c->stream_c) hipStreamDestroy(c->stream_c);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
@@ -188,10 +243,15 @@ static void free_all(oatgpu_ctx *c)
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
     }
     for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
-    for (auto sb : c->stream_b) if (sb) hipStreamDestroy(sb);
     for (auto e : c->ring_ev) hipEventDestroy(e);
     for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->private_streams) {
+        for (auto sb : c->stream_b) if (sb) hipStreamDestroy(sb);
+        if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+        if (c->stream_c) hipStreamDestroy(c->stream_c);
+    } else if (c->have_shared) {
+        release_streams(c->cfg.device);
+    }
     delete c;
 }
 
@@ -242,15 +302,18 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
 
     bool ok = true;
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
-    ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    c->own_stream = ok;
-    {   // stream B carries short latency-bound kernels that must slip in between the big
-        // bandwidth-bound launches of stream A: give it the highest priority
+    if (const char *e = getenv("OATGPU_NB")) { const int v = atoi(e); if (v >= 1 && v <= oatgpu_ctx::kNB) c->nb = v; }
+    c->private_streams = getenv("OATGPU_PRIVATE_STREAMS") != nullptr;     // measurement aid: the old layout
+    if (c->private_streams) {
+        ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+        c->own_stream = ok;
         int least = 0, greatest = 0;
         if (ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-        if (const char *e = getenv("OATGPU_NB")) { const int v = atoi(e); if (v >= 1 && v <= oatgpu_ctx::kNB) c->nb = v; }
         for (int q = 0; q < c->nb; ++q)
             ok = ok && hipStreamCreateWithPriority(&c->stream_b[q], hipStreamNonBlocking, greatest) == hipSuccess;
+    } else {
+        ok = acquire_streams(cfg->device, c->nb, &c->stream, c->stream_b);
+        c->have_shared = ok;
     }
     c->expt = getenv("OATGPU_EXPT") ? atoi(getenv("OATGPU_EXPT")) : 0;   // measurement aid (bit mask)
     c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
@@ -738,7 +801,9 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels, sb = fb * n;
     if (!c->frames_ring) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+        if (c->private_streams) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+        else c->stream_c = acquire_copy_stream(c->cfg.device);
+        if (!c->stream_c) return fail(c, OATGPU_E_HIP, "could not create the copy stream");
         HIPCHK(c, hipMalloc((void **)&c->frames_ring, sb * c->ring_slots));
         c->copy_ev.resize(c->ring_slots);
         for (auto &e : c->copy_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));

@@ -2,7 +2,7 @@
 // (no Python, no torch): what a native caller of liboatgpu.so sees per step.
 //   hipcc --offload-arch=gfx950 -O2 -w tools/bench_native.hip -Iinclude -Loat_amd/lib -loatgpu \
 //         -Wl,-rpath,'$ORIGIN/../../oat_amd/lib' -o build/bin/bench_native
-//   build/bin/bench_native ROWS COLS STREAMS STEPS [ERODE DILATE]
+//   build/bin/bench_native ROWS COLS STREAMS STEPS [ERODE DILATE [CONTEXTS]]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -49,8 +49,14 @@ int main(int argc, char **argv)
     cfg.erode = argc > 5 ? atoi(argv[5]) : 3;
     cfg.dilate = argc > 6 ? atoi(argv[6]) : 7;
     cfg.min_area = 20.0; cfg.max_area = 1e7;
-    oatgpu_ctx *c = oatgpu_create(&cfg);
-    if (!c) { fprintf(stderr, "create: %s\n", oatgpu_last_error(nullptr)); return 1; }
+    const int nctx = argc > 7 ? atoi(argv[7]) : 1;     // contexts driven round-robin from this thread
+    std::vector<oatgpu_ctx *> ctxs;
+    for (int i = 0; i < nctx; ++i) {
+        oatgpu_ctx *ci = oatgpu_create(&cfg);
+        if (!ci) { fprintf(stderr, "create: %s\n", oatgpu_last_error(nullptr)); return 1; }
+        ctxs.push_back(ci);
+    }
+    oatgpu_ctx *c = ctxs[0];
 
     const int pool_n = 48;
     const size_t fbytes = (size_t)ns * rows * cols * 3;
@@ -67,32 +73,35 @@ int main(int argc, char **argv)
     auto loop = [&](int n, bool count) {
         int rc = 0;
         for (int i = 0; i < n && !rc; ++i) {
-            if (oatgpu_track_outstanding(c) == cfg.ring_depth) {
-                rc = oatgpu_track_collect(c, pos.data());
-                if (count) for (auto &p : pos) found += p.valid;
+            for (oatgpu_ctx *ci : ctxs) {
+                if (oatgpu_track_outstanding(ci) == cfg.ring_depth) {
+                    rc = oatgpu_track_collect(ci, pos.data());
+                    if (count && ci == c) for (auto &p : pos) found += p.valid;
+                }
+                if (!rc) rc = oatgpu_track_enqueue_dev(ci, pool[i % pool_n], lr);
             }
-            if (!rc) rc = oatgpu_track_enqueue_dev(c, pool[i % pool_n], lr);
         }
-        while (!rc && oatgpu_track_outstanding(c)) {
-            rc = oatgpu_track_collect(c, pos.data());
-            if (count) for (auto &p : pos) found += p.valid;
-        }
+        for (oatgpu_ctx *ci : ctxs)
+            while (!rc && oatgpu_track_outstanding(ci)) {
+                rc = oatgpu_track_collect(ci, pos.data());
+                if (count && ci == c) for (auto &p : pos) found += p.valid;
+            }
         if (rc) { fprintf(stderr, "track: %s\n", oatgpu_last_error(c)); exit(1); }
     };
     loop(200, false);
-    oatgpu_synchronize(c);
+    for (oatgpu_ctx *ci : ctxs) oatgpu_synchronize(ci);
     oatgpu_profile_enable(c, 8);
     const double t0 = now_us();
     loop(steps, true);
-    oatgpu_synchronize(c);
+    for (oatgpu_ctx *ci : ctxs) oatgpu_synchronize(ci);
     const double t1 = now_us();
     oatgpu_profile pr;
     oatgpu_profile_read(c, &pr);
     const double us = (t1 - t0) / steps;
     printf("{\"rows\": %d, \"cols\": %d, \"streams\": %d, \"steps\": %d, \"us_per_step\": %.2f, \"fps\": %.1f, "
            "\"found\": %ld, \"expected\": %ld, \"k1_us\": %.2f, \"blob_us\": %.2f}\n",
-           rows, cols, ns, steps, us, ns * 1e6 / us, found, (long)steps * ns,
+           rows, cols, ns * nctx, steps, us, ns * nctx * 1e6 / us, found, (long)steps * ns,
            pr.steps ? 1e3 * (pr.mog_ms / pr.steps - pr.event_pair_ms) : 0.0, pr.steps ? 1e3 * pr.blob_ms / pr.steps : 0.0);
-    oatgpu_destroy(c);
+    for (oatgpu_ctx *ci : ctxs) oatgpu_destroy(ci);
     return 0;
 }
