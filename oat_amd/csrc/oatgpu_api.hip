@@ -34,7 +34,9 @@ struct oatgpu_ctx {
     bool private_streams = false;   // OATGPU_PRIVATE_STREAMS: streams of its own instead of the device's shared ones
     bool have_shared = false;
     static constexpr int kNB = 4;
-    int nb = 2;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
+    int nb = 3;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
+    bool b_used[kNB] = {};          // B streams this context has launched on (an untouched HIP stream has no
+                                    // hardware queue yet, and the number of queues in a process matters)
     hipStream_t stream_b[kNB] = {}; // streams B0/B1: morphology + blob analysis of even/odd frames,
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[kNB] = {};    // K1 of parity q finished (thr[q] is ready)
@@ -165,33 +167,51 @@ static MogParams mogparams_of(const oatgpu_config &k)
     return m;
 }
 
-// The HIP streams are shared by all contexts of a device in this process.  Measured on MI355X /
-// ROCm 7.2: with five or more ACTIVE HIP streams in one process every kernel -- K1 included -- runs
-// 2-4x slower (two contexts with private streams: 18.9k fps together, against 38.3k fps for one context
-// with both cameras), whatever GPU_MAX_HW_QUEUES says.  With one A and kNB B streams per device the
-// process stays at three (four with the host-frame copy stream) however many contexts it holds;
-// contexts then serialise on them, which costs nothing because each of their kernels fills the GPU.
+// The HIP streams are shared by all contexts of a device in this process, and they are created
+// together, in a fixed order.  Measured on MI355X / ROCm 7.2: the runtime
+// spreads the streams of a process over FOUR hardware queues in the order they are created (the
+// null stream counts from its first use; priorities and GPU_MAX_HW_QUEUES make no difference), and
+// two streams on one hardware queue execute strictly one after the other.  A fifth stream therefore
+// lands on the first one's queue: with private streams the second context's B0 shared a queue with
+// the first context's A, and every K1 waited for the other context's back halves (18.9k fps for two
+// contexts, against 38.3k for one context holding both cameras).  So: A, B0, B1, B2 are created
+// back to back (any four consecutive streams sit on four different queues) and shared by all
+// contexts; the host-frame copy stream is placed, with idle padding streams, on the queue of the
+// last B stream, which the host-frame path then leaves unused.
 namespace {
 struct DeviceStreams {
-    int refs = 0;
+    int refs = 0, nb = 0;
     hipStream_t a = nullptr, b[oatgpu_ctx::kNB] = {}, copy = nullptr;
+    std::vector<hipStream_t> padding;
 };
 std::mutex g_streams_mutex;
 std::map<int, DeviceStreams> g_streams;      // by device ordinal
+
+hipStream_t create_b_stream()
+{
+    // the B streams carry short latency-bound kernels that must slip in between the big
+    // bandwidth-bound launches of stream A: highest priority
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) st = nullptr;
+    return st;
+}
 
 bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
 {
     std::lock_guard<std::mutex> lk(g_streams_mutex);
     DeviceStreams &d = g_streams[device];
-    bool ok = true;
-    if (!d.a) ok = hipStreamCreateWithFlags(&d.a, hipStreamNonBlocking) == hipSuccess;
-    // the B streams carry short latency-bound kernels that must slip in between the big
-    // bandwidth-bound launches of stream A: highest priority
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-    for (int q = 0; q < nb && ok; ++q)
-        if (!d.b[q]) ok = hipStreamCreateWithPriority(&d.b[q], hipStreamNonBlocking, greatest) == hipSuccess;
-    if (!ok) return false;
+    if (!d.a) {
+        if (hipStreamCreateWithFlags(&d.a, hipStreamNonBlocking) != hipSuccess) { d.a = nullptr; return false; }
+        for (int q = 0; q < oatgpu_ctx::kNB - 1; ++q)            // A + 3 B streams = the four queues
+            if (!(d.b[q] = create_b_stream())) return false;
+        d.nb = oatgpu_ctx::kNB - 1;
+    }
+    for (int q = d.nb; q < nb; ++q) {                             // OATGPU_NB=4: measurement only
+        if (!(d.b[q] = create_b_stream())) return false;
+        d.nb = q + 1;
+    }
     d.refs++;
     *a = d.a;
     for (int q = 0; q < nb; ++q) b[q] = d.b[q];
@@ -201,7 +221,16 @@ hipStream_t acquire_copy_stream(int device)
 {
     std::lock_guard<std::mutex> lk(g_streams_mutex);
     DeviceStreams &d = g_streams[device];
-    if (!d.copy && hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking) != hipSuccess) d.copy = nullptr;
+    if (d.copy) return d.copy;
+    // streams created so far: A, B0..B(nb-1).  Pad so that the copy stream's index is congruent to
+    // the last B stream's modulo 4 (with A, B0, B1, B2: three idle padding streams, then the copy stream)
+    int pad = (1 + d.nb >= 4) ? 3 : 0;
+    if (const char *e = getenv("OATGPU_COPY_PAD")) pad = atoi(e);
+    for (int i = 0; i < pad; ++i) {
+        hipStream_t p = nullptr;
+        if (hipStreamCreateWithFlags(&p, hipStreamNonBlocking) == hipSuccess) d.padding.push_back(p);
+    }
+    if (hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking) != hipSuccess) d.copy = nullptr;
     return d.copy;
 }
 void release_streams(int device)
@@ -213,6 +242,7 @@ void release_streams(int device)
     if (d.a) hipStreamDestroy(d.a);
     for (auto sb : d.b) if (sb) hipStreamDestroy(sb);
     if (d.copy) hipStreamDestroy(d.copy);
+    for (auto p : d.padding) hipStreamDestroy(p);
     g_streams.erase(it);
 }
 }  // namespace
@@ -307,10 +337,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (c->private_streams) {
         ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
         c->own_stream = ok;
-        int least = 0, greatest = 0;
-        if (ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-        for (int q = 0; q < c->nb; ++q)
-            ok = ok && hipStreamCreateWithPriority(&c->stream_b[q], hipStreamNonBlocking, greatest) == hipSuccess;
+        for (int q = 0; q < c->nb && ok; ++q) ok = (c->stream_b[q] = create_b_stream()) != nullptr;
     } else {
         ok = acquire_streams(cfg->device, c->nb, &c->stream, c->stream_b);
         c->have_shared = ok;
@@ -382,7 +409,7 @@ extern "C" void oatgpu_destroy(oatgpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto sb : c->stream_b) if (sb) hipStreamSynchronize(sb);
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) hipStreamSynchronize(c->stream_b[q]);
     free_all(c);
 }
 
@@ -415,7 +442,7 @@ extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
@@ -426,7 +453,7 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     return OATGPU_OK;
 }
 
@@ -476,7 +503,7 @@ static u64 *thr_buf(oatgpu_ctx *c, int parity)
 static int quiesce(oatgpu_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto sb : c->stream_b) if (sb) HIPCHK(c, hipStreamSynchronize(sb));
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     return OATGPU_OK;
 }
 
@@ -755,7 +782,7 @@ static void prof_fold(oatgpu_ctx *c)
 {
     if (!c->prof_used) return;
     hipStreamSynchronize(c->stream);
-    for (auto sb : c->stream_b) if (sb) hipStreamSynchronize(sb);
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) hipStreamSynchronize(c->stream_b[q]);
     for (size_t i = 0; i < c->prof_used; ++i) {
         float a = 0, b = 0, d = 0, t = 0;
         ProfStep &p = c->prof_steps[i];
@@ -824,9 +851,13 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
     const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
-    const int q = slot % c->nb;                // scratch set / B stream of this frame
+    // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
+    // fewer then: the copy stream sits on the last B stream's hardware queue (see acquire_streams)
+    const int nbe = (frames_ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
+    const int q = slot % nbe;
     const int k = slot;                              // threshold-bit buffer of this frame
     hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
+    c->b_used[q] = true;
 
     ProfStep *ps = nullptr;
     if (c->prof && (c->prof_tick++ % (unsigned long long)c->prof_every) == 0) {

@@ -70,15 +70,20 @@ int main(int argc, char **argv)
     std::vector<oatgpu_position> pos(ns);
     const double lr = 0.01;
     long found = 0;
+    double t_enqueue = 0, t_collect = 0;       // host time inside the two calls
     auto loop = [&](int n, bool count) {
         int rc = 0;
         for (int i = 0; i < n && !rc; ++i) {
             for (oatgpu_ctx *ci : ctxs) {
                 if (oatgpu_track_outstanding(ci) == cfg.ring_depth) {
+                    const double x = now_us();
                     rc = oatgpu_track_collect(ci, pos.data());
+                    t_collect += now_us() - x;
                     if (count && ci == c) for (auto &p : pos) found += p.valid;
                 }
+                const double x = now_us();
                 if (!rc) rc = oatgpu_track_enqueue_dev(ci, pool[i % pool_n], lr);
+                t_enqueue += now_us() - x;
             }
         }
         for (oatgpu_ctx *ci : ctxs)
@@ -91,6 +96,7 @@ int main(int argc, char **argv)
     loop(200, false);
     for (oatgpu_ctx *ci : ctxs) oatgpu_synchronize(ci);
     oatgpu_profile_enable(c, 8);
+    t_enqueue = t_collect = 0;
     const double t0 = now_us();
     loop(steps, true);
     for (oatgpu_ctx *ci : ctxs) oatgpu_synchronize(ci);
@@ -99,9 +105,10 @@ int main(int argc, char **argv)
     oatgpu_profile_read(c, &pr);
     const double us = (t1 - t0) / steps;
     printf("{\"rows\": %d, \"cols\": %d, \"streams\": %d, \"steps\": %d, \"us_per_step\": %.2f, \"fps\": %.1f, "
-           "\"found\": %ld, \"expected\": %ld, \"k1_us\": %.2f, \"blob_us\": %.2f}\n",
+           "\"found\": %ld, \"expected\": %ld, \"k1_us\": %.2f, \"blob_us\": %.2f, \"host_enqueue_us\": %.2f, \"host_collect_us\": %.2f}\n",
            rows, cols, ns * nctx, steps, us, ns * nctx * 1e6 / us, found, (long)steps * ns,
-           pr.steps ? 1e3 * (pr.mog_ms / pr.steps - pr.event_pair_ms) : 0.0, pr.steps ? 1e3 * pr.blob_ms / pr.steps : 0.0);
+           pr.steps ? 1e3 * (pr.mog_ms / pr.steps - pr.event_pair_ms) : 0.0, pr.steps ? 1e3 * pr.blob_ms / pr.steps : 0.0,
+           t_enqueue / steps, t_collect / steps);
     for (oatgpu_ctx *ci : ctxs) oatgpu_destroy(ci);
     return 0;
 }
