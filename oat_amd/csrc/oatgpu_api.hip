@@ -37,7 +37,7 @@ struct oatgpu_ctx {
     int nb = 3;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
     bool b_used[kNB] = {};          // B streams this context has launched on (an untouched HIP stream has no
                                     // hardware queue yet, and the number of queues in a process matters)
-    hipStream_t stream_b[kNB] = {}; // streams B0/B1: morphology + blob analysis of even/odd frames,
+    hipStream_t stream_b[kNB] = {}; // streams B0..B2: morphology + blob analysis, frame t on B[t % nb],
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[kNB] = {};    // K1 of parity q finished (thr[q] is ready)
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
@@ -345,7 +345,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     c->expt = getenv("OATGPU_EXPT") ? atoi(getenv("OATGPU_EXPT")) : 0;   // measurement aid (bit mask)
     c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
     // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
-    // six plain launches on MI355X / ROCm 7.2 (profiles/r01_d_*): opt-in only.
+    // plain launches on MI355X / ROCm 7.2: opt-in only.
     c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
     c->ring_slots = cfg->ring_depth;                  // slot = threshold buffer, slot % nb = scratch set / stream
     for (int q = 0; q < c->nb && ok; ++q) {
@@ -796,8 +796,8 @@ static void prof_fold(oatgpu_ctx *c)
     c->prof_used = 0;
 }
 
-// Capture the back half of ring slot `slot` (buffers of parity slot & 1, result record of that slot)
-// into an executable graph: six dependent launches become one hipGraphLaunch of host work.
+// Capture the back half of ring slot `slot` (scratch set slot % nb, result record of that slot)
+// into an executable graph: the dependent launches become one hipGraphLaunch of host work.
 static hipGraphExec_t capture_back_half(oatgpu_ctx *c, int slot, hipStream_t B)
 {
     const int q = slot % c->nb;
