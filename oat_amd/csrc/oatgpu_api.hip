@@ -35,11 +35,10 @@ struct oatgpu_ctx {
     bool have_shared = false;
     static constexpr int kNB = 4;
     int nb = 3;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
-    bool b_used[kNB] = {};          // B streams this context has launched on (an untouched HIP stream has no
-                                    // hardware queue yet, and the number of queues in a process matters)
+    bool b_used[kNB] = {};          // B streams this context has launched on (the only ones it ever has to drain)
     hipStream_t stream_b[kNB] = {}; // streams B0..B2: morphology + blob analysis, frame t on B[t % nb],
                                                   // overlapped with later frames' per-pixel kernels and each other
-    hipEvent_t ev_k1[kNB] = {};    // K1 of parity q finished (thr[q] is ready)
+    hipEvent_t ev_k1[kNB] = {};    // the K1 whose back half runs on B[q] has finished (its threshold bits are ready)
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
