@@ -428,7 +428,7 @@ def main():
         "input": args.input,
         "dense_model": bool(args.dense_model),
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle meanwhile)
         line["cpu_baseline"] = cpu_baseline(wl, [p[0] for p in pool_host])
     else:
         line["cpu_baseline"] = None
