@@ -14,8 +14,10 @@
  *     oatgpu_last_error() gives the text.
  *   - the caller owns every host buffer; the context owns all device state
  *     (MOG2 model planes, bit masks, label tables, result ring).
- *   - one context per host thread (not re-entrant); work is issued on one HIP
- *     stream per context (oatgpu_set_stream adopts an external one).
+ *   - one context per host thread (not re-entrant).  The HIP streams the work is
+ *     issued on belong to the device and are shared by all contexts of a process
+ *     (DESIGN.md section 4); oatgpu_set_stream makes a context issue its per-pixel
+ *     kernel and copies on an external HIP stream instead.
  *   - pixel buffers are packed, rows*cols*channels bytes, no row padding
  *     (lib/datatypes/Frame.h:92-103, lib/shmemdf/Sink.h:289-290).
  *   - "stream" below = one camera stream (an independent Oat pipeline), not a
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 1
+#define OATGPU_ABI_VERSION 2     /* 2: oatgpu_position grew (filter outputs), new entry points */
 
 enum {
     OATGPU_OK = 0,
