@@ -45,6 +45,7 @@ class Profile(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
+ABI_VERSION = 2          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -121,7 +122,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.oatgpu_abi_version() != 1:
+    if lib.oatgpu_abi_version() != ABI_VERSION:
         raise ImportError("liboatgpu.so ABI version mismatch")
     _lib = lib
     return lib
