@@ -213,6 +213,9 @@ def main():
                     help="diagnostic: input that keeps all 5 mixture modes live on every pixel (K1 moves the full "
                          "205 B/px) and a threshold window nothing passes; not a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-calls", action="store_true",
+                    help="drive the pipelined path with one enqueue and one collect call per step from Python "
+                         "instead of one oatgpu_track_sequence_dev call for the whole run")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--check-steps", type=int, default=64,
                     help="timed steps of stream 0 replayed through the oracle after the run (0 = off)")
@@ -275,6 +278,15 @@ def main():
         else:
             host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool]
 
+    prepared, sequence_out = {}, []
+
+    def prepare(nsteps):
+        import ctypes as C
+        from oat_amd import ffi
+        if host_pool is None and not args.per_step_calls:
+            prepared[nsteps] = ((C.c_void_p * nsteps)(*[pool[(i + 1) % len(pool)].data_ptr() for i in range(nsteps)]),
+                                (ffi.Position * (nsteps * ns))())
+
     def run(nsteps, keep=False):
         if host_pool is not None and args.input == "host-sync":
             for i in range(nsteps):
@@ -282,12 +294,21 @@ def main():
                 if keep:
                     positions.append(r)
             return
-        # Thin loop straight on the C ABI: at ~45 us of HIP API time per step the Python wrapper's
-        # per-call object churn (a dataclass per position) would be a measurable part of a step, so the
-        # raw result records are kept and converted after the timed region.
         import ctypes as C
         from oat_amd import ffi
         lib, ctx, lr = hp.lib, hp.ctx, hp.learning_coeff_
+        if host_pool is None and not args.per_step_calls:
+            # Device-resident frames: the whole sequence through oatgpu_track_sequence_dev, i.e. the
+            # enqueue/collect loop inside the library -- at ~35 us per step two Python->C calls per step
+            # are a measurable part of it (--per-step-calls times them from Python instead).  The
+            # argument arrays are built by prepare() outside the timed region.
+            seq, out = prepared.pop(nsteps)
+            ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev(ctx, seq, nsteps, lr, out))
+            if keep:
+                sequence_out.append((out, nsteps))
+            return
+        # Thin loop straight on the C ABI; the raw result records are kept and converted after the
+        # timed region (a dataclass per position would be a measurable part of a step).
         enq, col = lib.oatgpu_track_enqueue_dev, lib.oatgpu_track_collect
         if host_pool is not None:
             enq_h = lib.oatgpu_track_enqueue
@@ -314,9 +335,11 @@ def main():
 
     # frame 1 initialises the models with the disc-free frame, then warm-up
     hp.track_dev(pool[0].data_ptr())
+    prepare(W)
     run(W)
     hp.profile(8)            # HIP events around K1 on every 8th step of the timed region
     hp.profile_reset()
+    prepare(K)
     barrier()
     t0 = time.perf_counter()
     run(K, keep=True)
@@ -326,6 +349,8 @@ def main():
     hp.profile(0)
     from oat_amd.components import Position2D
     positions.extend([Position2D.from_c(p) for p in buf] for buf in raw_results)
+    for out, nsteps in sequence_out:
+        positions.extend([Position2D.from_c(out[t * ns + s_]) for s_ in range(ns)] for t in range(nsteps))
 
     # parity gate on this run's own frames -- after the timed region, with fresh
     # contexts, so that it cannot disturb the measurement

@@ -232,6 +232,14 @@ int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double lea
  * until the matching oatgpu_track_collect returns. */
 int oatgpu_track_enqueue(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n, double learning_rate);
 int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
+
+/* A whole recorded sequence through the pipelined path in one call (what `oat frameserve file`
+ * feeding the chain amounts to, without a host round trip per frame): frames_dev[t] = frame set t
+ * in device memory (n_streams*rows*cols*channels bytes, stream-major), out[t*n_streams + s] = the
+ * result of stream s for frame t.  Equivalent to the enqueue/collect loop with the ring kept full;
+ * nothing may be outstanding when it is called. */
+int oatgpu_track_sequence_dev(oatgpu_ctx *ctx, const void *const *frames_dev, int32_t n_frames,
+                              double learning_rate, oatgpu_position *out);
 int oatgpu_track_outstanding(const oatgpu_ctx *ctx);
 
 /* ---- parity taps / model checkpoint (not in the reference; for tests and resume) ---- */

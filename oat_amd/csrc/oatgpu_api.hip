@@ -950,6 +950,28 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     return OATGPU_OK;
 }
 
+extern "C" int oatgpu_track_sequence_dev(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
+                                         oatgpu_position *out)
+{
+    if (!c || !frames_dev || !out || n_frames < 0) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "track_sequence while enqueued results are outstanding");
+    const int n = c->cfg.n_streams;
+    int got = 0;
+    for (int t = 0; t < n_frames; ++t) {
+        if (c->ring_count == c->cfg.ring_depth) {
+            const int rc = oatgpu_track_collect(c, out + (size_t)got++ * n);
+            if (rc) return rc;
+        }
+        const int rc = oatgpu_track_enqueue_dev(c, frames_dev[t], lr);
+        if (rc) return rc;
+    }
+    while (c->ring_count) {
+        const int rc = oatgpu_track_collect(c, out + (size_t)got++ * n);
+        if (rc) return rc;
+    }
+    return OATGPU_OK;
+}
+
 extern "C" int oatgpu_track_outstanding(const oatgpu_ctx *c) { return c ? c->ring_count : 0; }
 
 extern "C" int oatgpu_track_batch_dev(oatgpu_ctx *c, const void *frames_dev, double lr, oatgpu_position *out)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "oatgpu_track_batch_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_enqueue": (C.c_int, [_ctx, C.POINTER(_u8p), C.c_int32, C.c_double]),
     "oatgpu_track_enqueue_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double]),
+    "oatgpu_track_sequence_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_collect": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_track_outstanding": (C.c_int, [_ctx]),
     "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),

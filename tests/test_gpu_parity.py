@@ -843,3 +843,26 @@ def test_pipelined_host_frames_equal_the_synchronous_call(A):
         got.append(a.collect())
     assert got == want and sum(p.position_valid for r in got for p in r) >= 30
     _same_state(a.mog_state(1), b.mog_state(1)[:4])
+
+
+def test_track_sequence_equals_frame_by_frame(A):
+    """oatgpu_track_sequence_dev (the enqueue/collect loop inside the library) vs per-frame calls."""
+    import torch
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols, n, nframes = 90, 150, 2, 23
+    sts = [SyntheticStream(rows, cols, 70 + s, n_discs=1) for s in range(n)]
+    frames = [np.stack([st.frame(t, with_discs=t > 0) for st in sts]) for t in range(nframes)]
+    dev = torch.device("cuda:0")
+    bufs = [torch.from_numpy(f).to(dev) for f in frames]
+    torch.cuda.synchronize()
+    kw = dict(n_streams=n, adaptation_coeff=0.02, erode=3, dilate=5, area=(10.0, 1e5), **disc_hsv_window())
+    a = A.HotPath(rows, cols, ring_depth=5, **kw)
+    b = A.HotPath(rows, cols, **kw)
+    got = a.track_sequence_dev([t.data_ptr() for t in bufs])
+    want = [b.track(list(f)) for f in frames]
+    assert got == want and sum(p.position_valid for r in got for p in r) >= 30
+    assert a.track_sequence_dev([]) == []
+    a.enqueue_dev(bufs[0].data_ptr())
+    with pytest.raises(A.OatGpuError):
+        a.track_sequence_dev([bufs[1].data_ptr()])          # results outstanding
+    a.collect()

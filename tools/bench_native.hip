@@ -98,7 +98,15 @@ int main(int argc, char **argv)
     oatgpu_profile_enable(c, 8);
     t_enqueue = t_collect = 0;
     const double t0 = now_us();
-    loop(steps, true);
+    if (getenv("BENCH_SEQUENCE")) {        // the same loop inside the library
+        std::vector<const void *> seq(steps);
+        for (int i = 0; i < steps; ++i) seq[i] = pool[i % pool_n];
+        std::vector<oatgpu_position> all((size_t)steps * ns);
+        if (oatgpu_track_sequence_dev(c, seq.data(), steps, lr, all.data())) { fprintf(stderr, "%s\n", oatgpu_last_error(c)); return 1; }
+        for (auto &p : all) found += p.valid;
+    } else {
+        loop(steps, true);
+    }
     for (oatgpu_ctx *ci : ctxs) oatgpu_synchronize(ci);
     const double t1 = now_us();
     oatgpu_profile pr;

@@ -65,6 +65,18 @@ def run(n):
     return found
 
 
+def run_sequence(n):
+    seq = (C.c_void_p * n)(*[ptrs[i % len(ptrs)].value for i in range(n)])
+    out = (ffi.Position * (n * ns))()
+    t0 = time.perf_counter()
+    assert lib.oatgpu_track_sequence_dev(ctx, seq, n, 0.01, out) == 0
+    dt = time.perf_counter() - t0
+    print(f"  (inside the call: {dt / n * 1e6:.2f} us/step)")
+    return sum(out[i].valid for i in range(n * ns))
+
+
+if "--sequence" in sys.argv:
+    run = run_sequence
 run(200)
 lib.oatgpu_synchronize(ctx)
 t0 = time.perf_counter()
