@@ -23,10 +23,6 @@ import os
 import sys
 import time
 
-# The hot path keeps three HIP streams busy (per-pixel kernel + two back-half streams) beside torch's
-# own: ask the runtime for enough hardware queues that they never share one (must precede HIP init).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
