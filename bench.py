@@ -333,7 +333,7 @@ def main():
     hp.track_dev(pool[0].data_ptr())
     prepare(W)
     run(W)
-    hp.profile(8)            # HIP events around K1 on every 8th step of the timed region
+    hp.profile(16)           # HIP events around K1 on every 16th step of the timed region
     hp.profile_reset()
     prepare(K)
     barrier()

@@ -864,7 +864,7 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
             if (c->prof_steps.size() >= 1024) prof_fold(c);
             else {
                 ProfStep p;
-                for (auto &e : p.e) HIPCHK(c, hipEventCreate(&e));
+                for (auto &e : p.e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));   // timing, device-scope fence
                 c->prof_steps.push_back(p);
             }
         }
@@ -1215,8 +1215,8 @@ extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
         // (event processing + dispatch latency; the empty wave itself runs ~1 us)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipEvent_t e0, e1;
-        HIPCHK(c, hipEventCreate(&e0));
-        HIPCHK(c, hipEventCreate(&e1));
+        HIPCHK(c, hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+        HIPCHK(c, hipEventCreateWithFlags(&e1, hipEventDisableSystemFence));
         float best = 1e30f;
         for (int i = 0; i < 16; ++i) {
             HIPCHK(c, hipEventRecord(e0, c->stream));
