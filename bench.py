@@ -23,11 +23,6 @@ import os
 import sys
 import time
 
-# Eight hardware queues instead of the runtime's default four (read when HIP initialises, so it has
-# to be in the environment before torch touches the GPU): with four, the host-frame copy stream ends
-# up sharing a queue with compute and K1 runs 2.3x slower in --input host.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

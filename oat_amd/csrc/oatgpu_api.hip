@@ -175,20 +175,14 @@ static MogParams mogparams_of(const oatgpu_config &k)
 // the first context's A, and every K1 waited for the other context's back halves (18.9k fps for two
 // contexts, against 38.3k for one context holding both cameras).  So: A, B0, B1, B2 are created
 // back to back (any four consecutive streams sit on four different queues) and shared by all
-// contexts; the host-frame copy stream is placed, with idle padding streams, on the queue of the
-// last B stream, which the host-frame path then leaves unused.
+// contexts; the host-frame copy stream is created right behind them (the host-frame path leaves B2
+// unused, which keeps it at four active streams).
 namespace {
 struct DeviceStreams {
     int refs = 0, nb = 0;
     hipStream_t a = nullptr, b[oatgpu_ctx::kNB] = {}, copy = nullptr;
     std::vector<hipStream_t> padding;
 };
-// Best effort at load time (it only counts if the HIP runtime has not initialised yet, which is the
-// case for a program linked against this library): eight hardware queues instead of four, so that the
-// copy stream does not have to share one.  Measured: with the default of four, K1 runs 2.3x slower
-// while host frames are being copied, whatever the creation order; with eight it does not.
-__attribute__((constructor)) void oatgpu_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 std::mutex g_streams_mutex;
 std::map<int, DeviceStreams> g_streams;      // by device ordinal
 
@@ -212,10 +206,12 @@ bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
         for (int q = 0; q < oatgpu_ctx::kNB - 1; ++q)            // A + 3 B streams = the four queues
             if (!(d.b[q] = create_b_stream())) return false;
         d.nb = oatgpu_ctx::kNB - 1;
-        // ... and, in the same breath (a stream some other library creates in between would shift
-        // the placement), three idle padding streams and the host-frame copy stream, which thereby
-        // lands on B2's queue; the host-frame path leaves B2 unused.
-        int pad = 3;
+        // ... and, in the same breath, the host-frame copy stream.  Where it lands relative to A
+        // decides who yields while host frames are copied: right behind the B streams (no padding)
+        // the copies win and K1 waits for them, which is the better trade on a PCIe-bound path
+        // (7.8k fps at 1080p with K1 stretched to 62 us, against 5.6-7.0k fps with K1 at 26 us when
+        // OATGPU_COPY_PAD=1..3 idle streams are put in front of it).
+        int pad = 0;
         if (const char *e = getenv("OATGPU_COPY_PAD")) pad = atoi(e);
         for (int i = 0; i < pad; ++i) {
             hipStream_t p = nullptr;
