@@ -41,8 +41,10 @@ clean:
 .PHONY: all oracle host tools clean
 
 # A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> oat_amd/lib/liboatgpu_px2.so
+# Only these builds (-DOATGPU_MEASURE) read the OATGPU_EXPT / SERIAL / NB / ... measurement switches from the
+# environment; the product library ignores them.
 variant:
 	@mkdir -p build/$(NAME) oat_amd/lib
-	for f in kernels_mog kernels_blob kernels_kalman oatgpu_api; do $(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
+	for f in kernels_mog kernels_blob kernels_kalman oatgpu_api; do $(HIPCC) $(HIPFLAGS) -DOATGPU_MEASURE $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o oat_amd/lib/liboatgpu_$(NAME).so build/$(NAME)/*.o
 .PHONY: variant

@@ -41,6 +41,7 @@ WORKLOADS = {
     "vga1": dict(rows=480, cols=640, streams=1, erode=3, dilate=7),
 }
 ALPHA = 0.01
+RESTORE = 1                     # MOG2Invoker's `nmodes = nNewModes;` (oracle/mog2.c "Mode count"); 0 = the other reading
 AREA = (20.0, 1e5)
 
 
@@ -54,7 +55,7 @@ def make_hotpath(wl, device, ring_depth, dense=False):
     win = dict(h_thresh=(0, 256), s_thresh=(0, 256), v_thresh=(255, 256)) if dense else disc_hsv_window()
     return oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=wl["streams"], adaptation_coeff=ALPHA,
                            erode=wl["erode"], dilate=wl["dilate"], area=AREA, device=device,
-                           ring_depth=ring_depth, **win)
+                           ring_depth=ring_depth, mog_restore_nmodes=RESTORE, **win)
 
 
 def oracle_params(wl):
@@ -70,8 +71,8 @@ def parity_gate(wl, device, frames_seq):
     import oat_amd
     from oat_amd.synth import disc_hsv_window
     hp = oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=1, adaptation_coeff=ALPHA, erode=wl["erode"],
-                         dilate=wl["dilate"], area=AREA, device=device, **disc_hsv_window())
-    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+                         dilate=wl["dilate"], area=AREA, device=device, mog_restore_nmodes=RESTORE, **disc_hsv_window())
+    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
     p = oracle_params(wl)
     for t, f in enumerate(frames_seq):
         got = hp.track([f])[0]
@@ -92,7 +93,7 @@ def measured_run_gate(wl, frames_of_step, got_positions, nthreads):
     sequence (model init, warm-up, timed steps).  frames_of_step: host frames of stream 0 in run
     order; got_positions: (step index in that order, Position2D) pairs to compare."""
     import oracle_lib as O
-    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
     p = oracle_params(wl)
     want = [O.chain_step(orc, f, ALPHA, p, nthreads=nthreads)[0] for f in frames_of_step]
     for t, g in got_positions:
@@ -110,7 +111,7 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
     import oracle_lib as O
     # the port spawns its row workers per stage (no pool): beyond ~32 threads creation cost eats the gain
     ncores = min(os.cpu_count() or 1, 32)
-    orc = O.Mog2(wl["rows"], wl["cols"], 3)
+    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
     p = oracle_params(wl)
     O.chain_step(orc, frames_seq[0], ALPHA, p, nthreads=ncores)      # frame 1 (model init), untimed
     n = 0
@@ -217,8 +218,12 @@ def main():
                     help="timed steps of stream 0 replayed through the oracle after the run (0 = off)")
     ap.add_argument("--learning-rate", type=float, default=None,
                     help="MOG2 adaptation coefficient (default 0.01 = SURVEY 8d; 0 = Oat's default, frozen model)")
+    ap.add_argument("--mog-restore-nmodes", type=int, default=1, choices=[0, 1],
+                    help="1 (default): MOG2Invoker's `nmodes = nNewModes;` -- pruned modes keep their slot; 0: pruning "
+                         "shrinks the mode count (round 1's reading); oracle/mog2.c 'Mode count'")
     args = ap.parse_args()
-    global ALPHA
+    global ALPHA, RESTORE
+    RESTORE = args.mog_restore_nmodes
     if args.learning_rate is not None:
         ALPHA = args.learning_rate
 

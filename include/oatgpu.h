@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 2     /* 2: oatgpu_position grew (filter outputs), new entry points */
+#define OATGPU_ABI_VERSION 3     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes */
 
 enum {
     OATGPU_OK = 0,
@@ -85,6 +85,15 @@ typedef struct oatgpu_config {
     /* --- posidet diff (DifferenceDetector.h:63-76) --- */
     int32_t diff_threshold;    /* -d, default 10                              */
     int32_t blur;              /* -b, default 2; 0 = off; <= 22 supported     */
+
+    /* --- MOG2 mode count (MOG2Invoker's `nmodes = nNewModes;`) --- */
+    int32_t mog_restore_nmodes; /* 1 (default): the per-pixel mode count is set back to its value at
+                                  entry after the weight renormalisation, as cv::BackgroundSubtractorMOG2
+                                  does -- a pruned mode keeps its slot with weight 0 and modesUsed never
+                                  shrinks; 0: a pruned mode leaves the count (round 1's reading).
+                                  oracle/mog2.c "Mode count" has the derivation; no OpenCV is available
+                                  here to settle it, hence a switch rather than a constant. */
+    int32_t reserved_;
 } oatgpu_config;
 
 /* What posidet writes into oat::Position2D (src/positiondetector/DetectorFunc.cpp:46,58-60)

@@ -8,21 +8,22 @@
 // in ONE pass over HBM: 3 B/px of BGR in, the 101 B/px Gaussian-mixture model
 // read and written in place, 1 bit/px of threshold mask out.  Bandwidth bound
 // (205 algorithmic B/px); no MFMA.  Design notes:
-//   * one lane owns four pixels 64 apart (see mog_slot in oatgpu_internal.h):
-//     every model plane is one 16-byte load and one 16-byte store per lane,
-//     and __ballot() over pixel j of the 64 lanes IS mask word j -- the
-//     threshold image never exists as bytes.
+//   * one lane = one pixel, one wavefront = 64 consecutive pixels = one mask word:
+//     __ballot(thr) IS the word -- the threshold image never exists as bytes.
 //   * the per-pixel update keeps OpenCV's operation order exactly (compiled
 //     with -ffp-contract=off: every mul/add rounds on its own, like the
 //     reference's x86-64 build); the mixture lives in registers with fully
 //     unrolled, statically indexed mode loops (no scratch).
 //   * BGR->HSV uses the same integer tables as RGB2HSV_b, built once per block
 //     in LDS.
-//   * the model is sparse in practice (most pixels keep 1-2 of the 5 modes, and
-//     a frame changes only the matched mode's mean/variance): each lane loads
-//     only the planes of modes it has (exec-masked 16-byte loads; planes no lane
-//     of the wave needs are skipped outright) and writes back only planes whose
-//     bits changed.  The state in HBM stays bit-identical to updating all of it.
+//   * the model is sparse in practice and the kernel moves only what the arithmetic can
+//     depend on, in TWO load phases: (1) counter byte + mode 0 + the pixel, for every lane;
+//     then the loop's mode-0 iteration runs, which tells whether the pixel matched mode 0 as
+//     background; (2) of slots 1..n-1: the weight of LIVE slots (non-zero weight, hinted in
+//     the counter byte), and variance/mean only on lanes that did NOT match ("needy": only
+//     they can test, revive or overwrite a later mode, or run the shadow test).  Stores go
+//     out only for planes whose bits changed.  The state in HBM stays bit-identical to
+//     updating all of it (state-parity tests).
 #include "oatgpu_internal.h"
 
 namespace oatgpu {
@@ -31,6 +32,13 @@ struct PxModel {
     float w[kMaxMix];
     float v[kMaxMix];
     float m[kMaxMix][3];
+};
+
+// running state of MOG2Invoker's per-pixel mode loop (OpenCV 3.1.0 bgfg_gaussmix2.cpp)
+struct PxLoop {
+    bool background, fits;
+    int nmodes;        // the reference's `nmodes`: loop bound, shrinks when a mode is pruned
+    float total;
 };
 
 template <int CH>
@@ -44,76 +52,81 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // e
     for (int c = 0; c < CH; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
 }
 
-// MOG2Invoker's per-pixel body (OpenCV 3.1.0 bgfg_gaussmix2.cpp) on a register
-// resident mixture.  Returns the foreground-mask value {0, shadowVal, 255}.
-// dvm: bit k set when mode k's variance/mean registers were written; wchg: weights may differ
-// from what was loaded (false only when alpha == 0 and the renormalisation was by exactly 1).
+// Iteration MODE of the mode loop on a register resident mixture.
+// dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
 // 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
-template <int CH>
-__device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, float x1, float x2,
-                                          const MogParams &P, float alphaT, float alpha1, float prune,
-                                          unsigned &dvm, bool &wchg)
+template <int CH, int MODE>
+__device__ __forceinline__ void mog2_mode(PxModel &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
+                                          float alphaT, float alpha1, float prune, unsigned &dvm)
 {
-    bool background = false, fits = false;
-    int nmodes = nmodes_io;
-    float total = 0.f;
-
+    if (MODE < c.nmodes) {                // nmodes shrinks when a mode is pruned, as in the reference loop
+        float weight = alpha1 * s.w[MODE] + prune;
+        bool fit_here = false;
+        if (!c.fits) {
+            const float var = s.v[MODE];
+            const float d0 = s.m[MODE][0] - x0;
+            const float d1 = CH == 3 ? s.m[MODE][1] - x1 : 0.f;
+            const float d2 = CH == 3 ? s.m[MODE][2] - x2 : 0.f;
+            const float dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
+            if (c.total < P.TB && dist2 < P.Tb * var) c.background = true;
+            if (dist2 < P.Tg * var) {
+                c.fits = true;
+                fit_here = true;
+                weight += alphaT;
+                const float k = alphaT / weight;
+                s.m[MODE][0] -= k * d0;
+                if (CH == 3) { s.m[MODE][1] -= k * d1; s.m[MODE][2] -= k * d2; }
+                float varnew = var + k * (dist2 - var);
+                varnew = varnew > P.varMin ? varnew : P.varMin;
+                varnew = varnew < P.varMax ? varnew : P.varMax;
+                s.v[MODE] = varnew;
+                dvm |= (1u << MODE);
+                // The reference bubbles the OLD weight up and then stores the new one
+                // into the final slot; carrying the new weight along is the same state.
+                s.w[MODE] = weight;
+                bool moving = true;
 #pragma unroll
-    for (int mode = 0; mode < kMaxMix; ++mode) {
-        if (mode < nmodes) {              // nmodes shrinks when a mode is pruned, as in the reference loop
-            float weight = alpha1 * s.w[mode] + prune;
-            bool fit_here = false;
-            if (!fits) {
-                const float var = s.v[mode];
-                const float d0 = s.m[mode][0] - x0;
-                const float d1 = CH == 3 ? s.m[mode][1] - x1 : 0.f;
-                const float d2 = CH == 3 ? s.m[mode][2] - x2 : 0.f;
-                const float dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
-                if (total < P.TB && dist2 < P.Tb * var) background = true;
-                if (dist2 < P.Tg * var) {
-                    fits = true;
-                    fit_here = true;
-                    weight += alphaT;
-                    const float k = alphaT / weight;
-                    s.m[mode][0] -= k * d0;
-                    if (CH == 3) { s.m[mode][1] -= k * d1; s.m[mode][2] -= k * d2; }
-                    float varnew = var + k * (dist2 - var);
-                    varnew = varnew > P.varMin ? varnew : P.varMin;
-                    varnew = varnew < P.varMax ? varnew : P.varMax;
-                    s.v[mode] = varnew;
-                    dvm |= (1u << mode);
-                    // The reference bubbles the OLD weight up and then stores the new one
-                    // into the final slot; carrying the new weight along is the same state.
-                    s.w[mode] = weight;
-                    bool moving = true;
-#pragma unroll
-                    for (int i = mode; i > 0; --i) {
-                        if (moving) {
-                            if (weight < s.w[i - 1]) moving = false;
-                            else swap_up<CH>(s, i, dvm);
-                        }
+                for (int i = MODE; i > 0; --i) {
+                    if (moving) {
+                        if (weight < s.w[i - 1]) moving = false;
+                        else swap_up<CH>(s, i, dvm);
                     }
                 }
             }
-            if (!fit_here) {
-                // (a matched mode has weight >= alpha*(1-CT) > -prune: never pruned)
-                if (weight < -prune) { weight = 0.f; nmodes--; }
-                s.w[mode] = weight;
-            }
-            total += weight;
         }
+        if (!fit_here) {
+            // (a matched mode has weight >= alpha*(1-CT) > -prune for CT < 0.5 -- enforced by
+            // oatgpu_create -- so it is never pruned)
+            if (weight < -prune) { weight = 0.f; c.nmodes--; }
+            s.w[MODE] = weight;
+        }
+        c.total += weight;
     }
+}
 
+// Everything behind the mode loop: renormalisation, `nmodes = nNewModes;`, the new mode, the mask.
+// nentry: mode count at entry (the reference's nNewModes).  Returns the foreground-mask value
+// {0, shadowVal, 255}; nmodes_out: the count to store; wchg: weights may differ from what was loaded
+// (false only when alpha == 0 and the renormalisation was by exactly 1).
+template <int CH>
+__device__ __forceinline__ int mog2_finish(PxModel &s, PxLoop &c, int nentry, int &nmodes_out, float x0, float x1,
+                                           float x2, const MogParams &P, float alphaT, float alpha1, unsigned &dvm,
+                                           bool &wchg)
+{
+    int nmodes = c.nmodes;
     // renormalise
-    const float inv = 1.f / total;
+    const float inv = 1.f / c.total;
     wchg = (alphaT > 0.f) || (inv != 1.f);
 #pragma unroll
     for (int mode = 0; mode < kMaxMix; ++mode)
         if (mode < nmodes) s.w[mode] *= inv;
 
+    // `nmodes = nNewModes;`: pruned modes keep their slot (weight 0), the count never shrinks
+    if (P.restoreCount) nmodes = nentry;
+
     // new mode
-    if (!fits && alphaT > 0.f) {
+    if (!c.fits && alphaT > 0.f) {
         const int mode = (nmodes == P.nmix) ? P.nmix - 1 : nmodes++;
         const bool first = (nmodes == 1);
 #pragma unroll
@@ -136,9 +149,9 @@ __device__ __forceinline__ int mog2_pixel(PxModel &s, int &nmodes_io, float x0, 
             }
         }
     }
-    nmodes_io = nmodes;
+    nmodes_out = nmodes;
 
-    if (background) return 0;
+    if (c.background) return 0;
     int mask = 255;
     if (P.detectShadows) {
         // detectShadowGMM
@@ -205,41 +218,31 @@ __device__ __forceinline__ bool in_range3(int a, int b, int c, const RangeParams
            c >= rp.lo[2] && c <= rp.hi[2];
 }
 
-template <int N> struct VecOf;
-template <> struct VecOf<4> { typedef float4 F; typedef uchar4 B; };
-template <> struct VecOf<2> { typedef float2 F; typedef uchar2 B; };
-template <> struct VecOf<1> { typedef float F; typedef unsigned char B; };
-typedef VecOf<kPX>::F vecf;
-typedef float nvecf __attribute__((ext_vector_type(kPX)));   // native vector for the nontemporal builtins
-
-// Model plane access.  OATGPU_NT=1 marks the streamed planes nontemporal (A/B option).
+// Model plane access.  OATGPU_NT=1 marks the streamed planes nontemporal (A/B option: the bare access
+// pattern likes it, tools/k1_lab.hip; the kernel does not -- the Infinity Cache keeps much of a sparse
+// model across frames and the streaming policy gives that up: 4K 100 -> 116-120 us, r02 ab1).
 #ifndef OATGPU_NT
 #define OATGPU_NT 0
 #endif
-__device__ __forceinline__ void ld_plane(float *dst, const float *src)
+__device__ __forceinline__ float ld_plane(const float *src)
 {
 #if OATGPU_NT
-    *(nvecf *)dst = __builtin_nontemporal_load((const nvecf *)src);
+    return __builtin_nontemporal_load(src);
 #else
-    *(vecf *)dst = *(const vecf *)src;
+    return *src;
 #endif
 }
-__device__ __forceinline__ void st_plane(float *dst, const float *src)
+__device__ __forceinline__ void st_plane(float *dst, float v)
 {
 #if OATGPU_NT
-    __builtin_nontemporal_store(*(const nvecf *)src, (nvecf *)dst);
+    __builtin_nontemporal_store(v, dst);
 #else
-    *(vecf *)dst = *(const vecf *)src;
+    *dst = v;
 #endif
 }
-typedef VecOf<kPX>::B vecb;
 
-// OATGPU_WAVES: minimum waves per SIMD the register allocator must leave room for (A/B knob).
-#ifndef OATGPU_WAVES
-#define OATGPU_WAVES 1
-#endif
 template <int CH>
-__global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     __shared__ int sdiv[256];
     __shared__ int hdiv[256];
@@ -252,158 +255,121 @@ __global__ __launch_bounds__(256, OATGPU_WAVES) void k_mog_fused(Geom g, MogLaun
     const size_t npx = (size_t)g.H * g.W;
     const uint8_t *frame = a.frames + (size_t)s * npx * CH;
     float *sbase = a.state + (size_t)s * mog_stream_floats(g.Palloc);
-    float *st = sbase + mog_plane_off(g.Palloc, 0, base) + kPX * lane;     // plane 0 of this wave's tile
-    const size_t PS = mog_plane_stride(g.Palloc);                           // plane k = st + k * PS
-#if OATGPU_TILED
-    uint8_t *nm = (uint8_t *)sbase + mog_count_off(g.Palloc, base) + kPX * lane;
+    float *st = sbase + mog_plane_off(g.Palloc, 0, base) + lane;           // slot 0 of this pixel
+    const size_t PS = mog_plane_stride(g.Palloc);                           // slot k = st + k * PS
+#if OATGPU_TILE
+    uint8_t *nm = (uint8_t *)sbase + mog_count_off(g.Palloc, base) + lane;
 #else
-    uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + kPX * lane;
+    uint8_t *nm = a.nmodes + (size_t)s * g.Palloc + base + lane;
 #endif
+    const int p = base + lane;
+    const int y = p / g.Wp;
+    const int x = p - y * g.Wp;
+    const bool valid = (p < g.P) && (x < g.W);
+    const size_t fi = ((size_t)y * g.W + x) * CH;
 
-    // ---- load the mixture of this lane's pixels: mode 0 right away (almost every pixel has
-    // it), modes 1..4 only where some pixel of the lane has them (exec-masked vector loads) ----
-    float W[kMaxMix][kPX], V[kMaxMix][kPX], M[kMaxMix][3][kPX];
-    int nmodes[kPX], nold[kPX];
+    // ---- phase 1: counter byte, mode 0, the pixel -- for every lane, nothing depends on anything ----
+    PxModel pm;
 #pragma unroll
-    for (int j = 0; j < kPX; ++j) nmodes[j] = 0;
-    if (active && !a.fresh) {
-        const vecb n4 = *(const vecb *)nm;
-        const uint8_t *nb = (const uint8_t *)&n4;
+    for (int k = 0; k < kMaxMix; ++k) { pm.w[k] = 0.f; pm.v[k] = 0.f; pm.m[k][0] = 0.f; pm.m[k][1] = 0.f; pm.m[k][2] = 0.f; }
+    int cnt = 0;
+    int b = 0, gg = 0, r = 0;
+    if (active) {
+        if (!a.fresh) {
+            cnt = *nm;
+            pm.w[0] = ld_plane(st + (size_t)slot_w(0) * PS);
+            pm.v[0] = ld_plane(st + (size_t)slot_v(0) * PS);
 #pragma unroll
-        for (int j = 0; j < kPX; ++j) nmodes[j] = nb[j];
-        ld_plane(W[0], st);
-        ld_plane(V[0], st + (size_t)5 * PS);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) ld_plane(M[0][c], st + (size_t)(10 + c) * PS);
-        if (CH == 1) {
-#pragma unroll
-            for (int j = 0; j < kPX; ++j) { M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
+            for (int c = 0; c < CH; ++c) pm.m[0][c] = ld_plane(st + (size_t)slot_m(0, c) * PS);
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kPX; ++j) { W[0][j] = 0.f; V[0][j] = 0.f; M[0][0][j] = 0.f; M[0][1][j] = 0.f; M[0][2][j] = 0.f; }
-    }
-    int nmax_old = 0;
-#pragma unroll
-    for (int j = 0; j < kPX; ++j) { nold[j] = nmodes[j]; nmax_old = max(nmax_old, nmodes[j]); }
-#pragma unroll
-    for (int k = 1; k < kMaxMix; ++k) {
-        if (k < nmax_old) {
-            ld_plane(W[k], st + (size_t)k * PS);
-            ld_plane(V[k], st + (size_t)(5 + k) * PS);
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                ld_plane(M[k][c], st + (size_t)(10 + 3 * k + c) * PS);
-            if (CH == 1) {
-#pragma unroll
-                for (int j = 0; j < kPX; ++j) { M[k][1][j] = 0.f; M[k][2][j] = 0.f; }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kPX; ++j) {
-                W[k][j] = 0.f; V[k][j] = 0.f; M[k][0][j] = 0.f; M[k][1][j] = 0.f; M[k][2][j] = 0.f;
-            }
-        }
-    }
-    unsigned dvm = 0;           // modes whose variance/mean changed for any of the lane's pixels
-    bool wchg = false;          // weights changed for any of the lane's pixels
-
-    // The HSV tables are built (integer divisions, LDS, one barrier) AFTER the model loads have
-    // been issued, so that their latency covers the table construction.
-    hsv_tables_init(sdiv, hdiv);
-    __syncthreads();
-    if (!active) return;
-
-    u64 words[kPX];
-#pragma unroll
-    for (int j = 0; j < kPX; ++j) {
-        const int p = base + 64 * j + lane;
-        const int y = p / g.Wp;
-        const int x = p - y * g.Wp;
-        const bool valid = (p < g.P) && (x < g.W);
-        const size_t fi = ((size_t)y * g.W + x) * CH;
-        int b = 0, gg = 0, r = 0;
         if (valid) {
             b = frame[fi];
             if (CH == 3) { gg = frame[fi + 1]; r = frame[fi + 2]; }
         }
-        // `framefilt mask` placed before mog (FrameMasker.cpp:71-75: frame.setTo(0, roi_mask == 0)):
-        // one bit per pixel, word j of this wave's tile covers pixel j of all 64 lanes.
-        if (a.roi_bits) {
-            const u64 rw = a.roi_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6) + j];
-            if (!((rw >> lane) & 1ull)) { b = 0; gg = 0; r = 0; }
-        }
-
-        PxModel pm;
-#pragma unroll
-        for (int k = 0; k < kMaxMix; ++k) {
-            pm.w[k] = W[k][j]; pm.v[k] = V[k][j];
-            pm.m[k][0] = M[k][0][j]; pm.m[k][1] = M[k][1][j]; pm.m[k][2] = M[k][2][j];
-        }
-        int n = nmodes[j];
-        int mask = 0;
-        if (valid) {
-            bool wc = false;
-            mask = mog2_pixel<CH>(pm, n, (float)b, (float)gg, (float)r, a.mp, a.alphaT, a.alpha1, a.prune, dvm, wc);
-            wchg |= wc;
-        }
-        nmodes[j] = n;
-#pragma unroll
-        for (int k = 0; k < kMaxMix; ++k) {
-            W[k][j] = pm.w[k]; V[k][j] = pm.v[k];
-            M[k][0][j] = pm.m[k][0]; M[k][1][j] = pm.m[k][1]; M[k][2][j] = pm.m[k][2];
-        }
-
-        // frame.setTo(0, mask == 0): shadows (127) stay foreground
-        if (mask == 0) { b = 0; gg = 0; r = 0; }
-        if (valid && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
-        if (valid && a.out_bgr) {
-            uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * CH + fi;
-            o[0] = (uint8_t)b;
-            if (CH == 3) { o[1] = (uint8_t)gg; o[2] = (uint8_t)r; }
-        }
-        bool thr;
-        if (CH == 3) {
-            int hh, ss, vv;
-            bgr2hsv_px(b, gg, r, sdiv, hdiv, hh, ss, vv);
-            thr = valid && in_range3(hh, ss, vv, a.rp);
-        } else {                                     // GREY chain: framefilt mog -> posidet thresh
-            thr = valid && b >= a.rp.lo[0] && b <= a.rp.hi[0];
-        }
-        words[j] = __ballot(thr);
     }
+
+    // The HSV tables are built (fp32 quotients, LDS, one barrier) AFTER the loads have been
+    // issued, so that their latency covers the table construction.
+    hsv_tables_init(sdiv, hdiv);
+    __syncthreads();
+    if (!active) return;
+
+    // `framefilt mask` placed before mog (FrameMasker.cpp:71-75: frame.setTo(0, roi_mask == 0)):
+    // one bit per pixel, one word per wave.
+    if (a.roi_bits) {
+        const u64 rw = a.roi_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6)];
+        if (!((rw >> lane) & 1ull)) { b = 0; gg = 0; r = 0; }
+    }
+
+    const int nold = cnt & kCountMask;
+    const float x0 = (float)b, x1 = (float)gg, x2 = (float)r;
+    PxLoop lp{false, false, nold, 0.f};
+    unsigned dvm = 0;           // modes whose variance/mean changed
+    bool wchg = false;          // weights changed
+    if (valid) mog2_mode<CH, 0>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+    // A pixel that matched mode 0 as background never looks at another mode's variance/mean again this
+    // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
+    // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
+    const bool full = valid && !(lp.fits && lp.background);
+
+    // ---- phase 2: slots 1..n-1 ----
+#pragma unroll
+    for (int k = 1; k < kMaxMix; ++k) {
+        const bool have = valid && k < nold;
+        if (have && ((cnt >> (kLiveShift + k)) & 1)) pm.w[k] = ld_plane(st + (size_t)slot_w(k) * PS);
+        if (have && full) {
+            pm.v[k] = ld_plane(st + (size_t)slot_v(k) * PS);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) pm.m[k][c] = ld_plane(st + (size_t)slot_m(k, c) * PS);
+        }
+    }
+
+    int mask = 0, nnew = nold;
+    if (valid) {
+        mog2_mode<CH, 1>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 2>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 3>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 4>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mask = mog2_finish<CH>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg);
+    }
+
+    // frame.setTo(0, mask == 0): shadows (127) stay foreground
+    if (mask == 0) { b = 0; gg = 0; r = 0; }
+    if (valid && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
+    if (valid && a.out_bgr) {
+        uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * CH + fi;
+        o[0] = (uint8_t)b;
+        if (CH == 3) { o[1] = (uint8_t)gg; o[2] = (uint8_t)r; }
+    }
+    bool thr;
+    if (CH == 3) {
+        int hh, ss, vv;
+        bgr2hsv_px(b, gg, r, sdiv, hdiv, hh, ss, vv);
+        thr = valid && in_range3(hh, ss, vv, a.rp);
+    } else {                                     // GREY chain: framefilt mog -> posidet thresh
+        thr = valid && b >= a.rp.lo[0] && b <= a.rp.hi[0];
+    }
+    const u64 word = __ballot(thr);
 
     // ---- store back only what changed (values not stored are bit-identical in HBM) ----
-    int nmax_new = 0;
-    bool nchg = a.fresh != 0;
-#pragma unroll
-    for (int j = 0; j < kPX; ++j) { nmax_new = max(nmax_new, nmodes[j]); nchg |= (nmodes[j] != nold[j]); }
-    const int nlive = max(nmax_old, nmax_new);
+    // Weights of slot k >= 1 can only have changed on a full lane (anything goes there) or where the
+    // slot was live (decay / renormalisation); a dead slot on a matched lane was 0 and still is.
+    const int nlive = max(nold, nnew);
+    int newcnt = nnew;
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
-        if (wchg && k < nlive)
-            st_plane(st + (size_t)k * PS, W[k]);
+        const bool was_live = k == 0 || full || ((cnt >> (kLiveShift + k)) & 1);
+        if (valid && wchg && k < nlive && was_live) st_plane(st + (size_t)slot_w(k) * PS, pm.w[k]);
         if ((dvm >> k) & 1u) {
-            st_plane(st + (size_t)(5 + k) * PS, V[k]);
+            st_plane(st + (size_t)slot_v(k) * PS, pm.v[k]);
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                st_plane(st + (size_t)(10 + 3 * k + c) * PS, M[k][c]);
+            for (int c = 0; c < CH; ++c) st_plane(st + (size_t)slot_m(k, c) * PS, pm.m[k][c]);
         }
+        if (k >= 1 && k < nnew && pm.w[k] != 0.f) newcnt |= 1 << (kLiveShift + k);
     }
-    if (nchg) {
-        vecb nv;
-        uint8_t *nb = (uint8_t *)&nv;
-#pragma unroll
-        for (int j = 0; j < kPX; ++j) nb[j] = (uint8_t)nmodes[j];
-        *(vecb *)nm = nv;
-    }
+    if (newcnt != cnt || a.fresh) *nm = (uint8_t)newcnt;
 
-    if (a.thr_bits && lane < kPX) {
-        u64 wsel = words[0];
-#pragma unroll
-        for (int j = 1; j < kPX; ++j) wsel = (lane == j) ? words[j] : wsel;
-        a.thr_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6) + lane] = wsel;
-    }
+    if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6)] = word;
 }
 
 // ---- achievable-bandwidth probes: the simplest possible streaming kernels ----
@@ -599,17 +565,17 @@ void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_
 __device__ __forceinline__ float *state_elem(const Geom &g, float *sbase, int plane, int p)
 {
     const int base = p - (p % kWavePx);
-    return sbase + mog_plane_off(g.Palloc, plane, base) + (mog_slot(p) - base);
+    return sbase + mog_plane_off(g.Palloc, plane, base) + (p - base);
 }
 __device__ __forceinline__ uint8_t *count_elem(const Geom &g, float *sbase, uint8_t *nmodes, int p)
 {
-#if OATGPU_TILED
+#if OATGPU_TILE
     const int base = p - (p % kWavePx);
     (void)nmodes;
-    return (uint8_t *)sbase + mog_count_off(g.Palloc, base) + (mog_slot(p) - base);
+    return (uint8_t *)sbase + mog_count_off(g.Palloc, base) + (p - base);
 #else
     (void)sbase;
-    return nmodes + mog_slot(p);
+    return nmodes + p;
 #endif
 }
 
@@ -621,12 +587,12 @@ __global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
         const int p = y * g.Wp + x;
-        modes_used[i] = *count_elem(g, state, nmodes, p);
+        modes_used[i] = *count_elem(g, state, nmodes, p) & kCountMask;     // the live hints stay inside
         for (int k = 0; k < nmix; ++k) {
-            weight[i * nmix + k] = *state_elem(g, state, k, p);
-            variance[i * nmix + k] = *state_elem(g, state, 5 + k, p);
+            weight[i * nmix + k] = *state_elem(g, state, slot_w(k), p);
+            variance[i * nmix + k] = *state_elem(g, state, slot_v(k), p);
             for (int c = 0; c < ch; ++c)
-                mean[(i * nmix + k) * ch + c] = *state_elem(g, state, 10 + 3 * k + c, p);
+                mean[(i * nmix + k) * ch + c] = *state_elem(g, state, slot_m(k, c), p);
         }
     }
 }
@@ -639,12 +605,15 @@ __global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
         const int p = y * g.Wp + x;
-        *count_elem(g, state, nmodes, p) = modes_used[i];
+        int cnt = modes_used[i];
+        for (int k = 1; k < nmix && k < (int)modes_used[i]; ++k)            // live hints of slots 1..n-1
+            if (weight[i * nmix + k] != 0.f) cnt |= 1 << (kLiveShift + k);
+        *count_elem(g, state, nmodes, p) = (uint8_t)cnt;
         for (int k = 0; k < nmix; ++k) {
-            *state_elem(g, state, k, p) = weight[i * nmix + k];
-            *state_elem(g, state, 5 + k, p) = variance[i * nmix + k];
+            *state_elem(g, state, slot_w(k), p) = weight[i * nmix + k];
+            *state_elem(g, state, slot_v(k), p) = variance[i * nmix + k];
             for (int c = 0; c < ch; ++c)
-                *state_elem(g, state, 10 + 3 * k + c, p) = mean[(i * nmix + k) * ch + c];
+                *state_elem(g, state, slot_m(k, c), p) = mean[(i * nmix + k) * ch + c];
         }
     }
 }

@@ -23,6 +23,20 @@ using namespace oatgpu;
 
 static thread_local std::string g_last_error;
 
+// Measurement switches (OATGPU_EXPT / SERIAL / NB / PRIVATE_STREAMS / COPY_PAD / GRAPH) exist only in
+// A/B builds made with -DOATGPU_MEASURE (`make variant`); the product library never reads them, so
+// nothing in the environment can change what it computes or skip work (tests/test_gpu_parity.py::
+// test_measurement_env_is_inert_in_the_product_library).
+static inline const char *measure_env(const char *name)
+{
+#ifdef OATGPU_MEASURE
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 struct ProfStep { hipEvent_t e[5]; };
 struct Rate { float alphaT, alpha1, prune; int fresh; };   // A: K1 begin/end; B: back-half begin, after erode, end
 
@@ -123,6 +137,7 @@ extern "C" int oatgpu_default_config(oatgpu_config *c)
     c->h_lo = 0; c->h_hi = 256; c->s_lo = 0; c->s_hi = 256; c->v_lo = 0; c->v_hi = 256;
     c->erode = 0; c->dilate = 10; c->min_area = 0.0; c->max_area = DBL_MAX;
     c->diff_threshold = 10; c->blur = 2;       // DifferenceDetector.h:74, DifferenceDetector.cpp:41
+    c->mog_restore_nmodes = 1;                 // bgfg_gaussmix2.cpp MOG2Invoker: nmodes = nNewModes
     return OATGPU_OK;
 }
 
@@ -163,6 +178,7 @@ static MogParams mogparams_of(const oatgpu_config &k)
     m.Tb = k.var_threshold; m.TB = k.background_ratio; m.Tg = k.var_threshold_gen;
     m.varInit = k.var_init; m.varMin = k.var_min; m.varMax = k.var_max; m.tau = k.tau;
     m.nmix = k.nmixtures; m.detectShadows = k.detect_shadows; m.shadowVal = k.shadow_value;
+    m.restoreCount = k.mog_restore_nmodes ? 1 : 0;
     return m;
 }
 
@@ -212,7 +228,7 @@ bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
         // (7.8k fps at 1080p with K1 stretched to 62 us, against 5.6-7.0k fps with K1 at 26 us when
         // OATGPU_COPY_PAD=1..3 idle streams are put in front of it).
         int pad = 0;
-        if (const char *e = getenv("OATGPU_COPY_PAD")) pad = atoi(e);
+        if (const char *e = measure_env("OATGPU_COPY_PAD")) pad = atoi(e);
         for (int i = 0; i < pad; ++i) {
             hipStream_t p = nullptr;
             if (hipStreamCreateWithFlags(&p, hipStreamNonBlocking) == hipSuccess) d.padding.push_back(p);
@@ -300,6 +316,10 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         fail(nullptr, OATGPU_E_INVALID, "nmixtures must be in 1..5");
         return nullptr;
     }
+    if (!(cfg->ct >= 0.f && cfg->ct < 0.5f)) {      // a matched mode must never be prunable (kernels_mog.hip mog2_mode)
+        fail(nullptr, OATGPU_E_INVALID, "ct (complexity reduction) must be in [0, 0.5)");
+        return nullptr;
+    }
     if ((long long)cfg->rows * (((long long)cfg->cols + 63) / 64 * 64) > 0x7fff0000ll) {
         fail(nullptr, OATGPU_E_INVALID, "frame too large");
         return nullptr;
@@ -332,8 +352,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
 
     bool ok = true;
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
-    if (const char *e = getenv("OATGPU_NB")) { const int v = atoi(e); if (v >= 1 && v <= oatgpu_ctx::kNB) c->nb = v; }
-    c->private_streams = getenv("OATGPU_PRIVATE_STREAMS") != nullptr;     // measurement aid: the old layout
+    if (const char *e = measure_env("OATGPU_NB")) { const int v = atoi(e); if (v >= 1 && v <= oatgpu_ctx::kNB) c->nb = v; }
+    c->private_streams = measure_env("OATGPU_PRIVATE_STREAMS") != nullptr;     // measurement aid: the old layout
     if (c->private_streams) {
         ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
         c->own_stream = ok;
@@ -342,11 +362,11 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = acquire_streams(cfg->device, c->nb, &c->stream, c->stream_b);
         c->have_shared = ok;
     }
-    c->expt = getenv("OATGPU_EXPT") ? atoi(getenv("OATGPU_EXPT")) : 0;   // measurement aid (bit mask)
-    c->serial = getenv("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
+    c->expt = measure_env("OATGPU_EXPT") ? atoi(measure_env("OATGPU_EXPT")) : 0;   // measurement aid (bit mask)
+    c->serial = measure_env("OATGPU_SERIAL") != nullptr;   // measurement aid: run the back half on stream A
     // Replaying the back half from a captured hipGraph is implemented but measured 0-5 % SLOWER than
     // plain launches on MI355X / ROCm 7.2: opt-in only.
-    c->use_graph = getenv("OATGPU_GRAPH") != nullptr && !c->serial;
+    c->use_graph = measure_env("OATGPU_GRAPH") != nullptr && !c->serial;
     c->ring_slots = cfg->ring_depth;                  // slot = threshold buffer, slot % nb = scratch set / stream
     for (int q = 0; q < c->nb && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;

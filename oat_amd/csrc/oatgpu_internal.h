@@ -25,61 +25,63 @@ struct Geom {
     int n_streams;
 };
 
-// MOG2 model layout in HBM (per stream): 25 fp32 planes + one u8 plane.
-//   plane 0..4   weight[k]
-//   plane 5..9   variance[k]
-//   plane 10+3k+c  mean[k][c]
-// Inside a plane the 256 pixels one wavefront owns are stored lane-interleaved:
-//   pixel p = base + 64*j + lane   (base multiple of 64*kPX, j in 0..kPX-1)
-//   slot    = base + kPX*lane + j
-// so one vector load per lane fetches that lane's kPX pixels (16 B/lane for
-// kPX = 4, 1 KiB per wave instruction) and pixels {base+64j .. base+64j+63} --
-// one mask word -- sit in component j of the 64 lanes.
+// MOG2 model in HBM (per stream): 25 fp32 planes + one u8 plane (mode counters), 101 B/px.
+// One lane of K1 owns one pixel (p = y*Wp + x), a wavefront 64 consecutive pixels = one mask word:
+// every plane access of a wave is one coalesced 256-byte line pair and __ballot(thr) IS the word.
+// (Round 1 measured 2 and 4 pixels per lane with 8/16-byte accesses: 108/165 VGPRs, 4/3 waves per
+// SIMD, slower; tools/k1_lab.hip shows the bare access pattern gains <= 3 % from wider accesses.)
+//
+// The counter byte of a pixel:  bits 0-2  modesUsed (what the reference keeps, 0..5)
+//                               bits 3-6  LIVE hints: bit 2+k set <=> slot k (k = 1..4) holds a
+//                                         weight that is not exactly 0
+// The hints are this kernel's own bookkeeping (exported state has bits 0-2 only).  With the
+// reference's `nmodes = nNewModes;` a pruned mode keeps its slot for ever with weight 0, so after a
+// while most pixels count 5 modes of which 1-2 are alive; a slot whose weight is 0 can only matter
+// to a pixel that has not matched an earlier mode (it may be re-matched and revived).  K1 therefore
+// loads, of slots >= 1, the weights of LIVE slots only, and variance/mean only for pixels that did
+// not match mode 0 as background ("needy" lanes) -- see k_mog_fused.
 constexpr int kMogPlanes = 25;
 constexpr int kMaxMix = 5;
-#ifndef OATGPU_PX
-#define OATGPU_PX 1
-#endif
-// Pixels per lane of the MOG kernel (1, 2 or 4).  Measured on MI355X at 4K: 4 px/lane (16-byte
-// loads, 165 VGPRs, 3 waves/SIMD) 138-145 us; 2 px/lane (108 VGPRs, 4 waves) 144 us; 1 px/lane (62 VGPRs,
-// 8 waves/SIMD, 4-byte loads) 113-123 us -- the kernel is latency-bound on its dependent load phases, so
-// occupancy beats load width.
-constexpr int kPX = OATGPU_PX;
-constexpr int kWavePx = 64 * kPX;         // pixels one wavefront owns
+constexpr int kWavePx = 64;               // pixels one wavefront owns
+constexpr int kCountMask = 7;
+constexpr int kLiveShift = 2;             // live bit of slot k is bit kLiveShift + k (k >= 1)
 
-__host__ __device__ inline int mog_slot(int p)
-{
-    int base = p - (p % kWavePx), r = p % kWavePx;
-    return base + kPX * (r & 63) + (r >> 6);
-}
-
-// Where the planes live.  TILED (OATGPU_TILED=1, an A/B option; measured 3-4 % slower on MI355X): everything one wavefront needs is ONE contiguous
-// ~26 KB record -- 25 fp32 planes of kWavePx entries, then kWavePx mode counters (bytes) --
-// so a wave's 26 vector loads hit consecutive DRAM pages and one TLB entry instead of 26
-// streams that are 33 MB apart.  PLANAR (default): plane-major arrays of Palloc
-// entries, counters in a separate array.
-#ifndef OATGPU_TILED
-#define OATGPU_TILED 0
+// Where the planes live.  Default (OATGPU_TILE = 0): plane-major arrays of Palloc entries, counters in
+// an array of their own.  OATGPU_TILE = 256 (A/B option): everything the 256 pixels of one K1 workgroup
+// need is ONE contiguous 25.25 KiB record -- 256 counter bytes, then the 25 planes of those pixels in
+// SLOT order.  The bare access pattern likes tiles + the streaming cache policy (6.45 TB/s against
+// 5.77 TB/s for plane-major, tools/k1_lab.hip, profiles/r02_k1_lab.txt); the real kernel does not
+// (profiles/r02_k1_layout_ab.txt: dense 4K K1 383 vs 400 us, but the everyday sparse model 109 vs 100 us,
+// and with nontemporal accesses 120 us): a sparse model's hot part -- mode 0 -- is 174 MB of dense
+// arrays at 4K, which the 256 MiB Infinity Cache keeps from frame to frame.
+// Slot order: the five planes of a mode are adjacent -- weight, variance, mean[3].
+#ifndef OATGPU_TILE
+#define OATGPU_TILE 0
 #endif
-#if OATGPU_TILED
-constexpr int kTileFloats = kMogPlanes * kWavePx + kWavePx / 4;
-__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)(Palloc / kWavePx) * kTileFloats; }
-// float offset (within a stream) of `plane` for the wave tile that starts at pixel `base`
-__host__ __device__ inline size_t mog_plane_off(int Palloc, int plane, int base)
+constexpr int kTilePx = OATGPU_TILE;
+static_assert(kTilePx == 0 || (kTilePx % kWavePx == 0 && 1024 % kTilePx == 0), "tile must hold whole wave tiles and divide Palloc");
+__host__ __device__ constexpr int slot_w(int k) { return 5 * k; }
+__host__ __device__ constexpr int slot_v(int k) { return 5 * k + 1; }
+__host__ __device__ constexpr int slot_m(int k, int c) { return 5 * k + 2 + c; }
+#if OATGPU_TILE
+constexpr int kTileFloats = kTilePx / 4 + kMogPlanes * kTilePx;
+__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)(Palloc / kTilePx) * kTileFloats; }
+// float offset (within a stream) of slot `slot` for the wave tile that starts at pixel `base`
+__host__ __device__ inline size_t mog_plane_off(int Palloc, int slot, int base)
 {
     (void)Palloc;
-    return (size_t)(base / kWavePx) * kTileFloats + (size_t)plane * kWavePx;
+    return (size_t)(base / kTilePx) * kTileFloats + kTilePx / 4 + (size_t)slot * kTilePx + (base % kTilePx);
 }
-__host__ __device__ inline size_t mog_plane_stride(int Palloc) { (void)Palloc; return kWavePx; }
-// byte offset (within a stream's float array) of the mode counters of that tile
+__host__ __device__ inline size_t mog_plane_stride(int Palloc) { (void)Palloc; return kTilePx; }
+// byte offset (within a stream's float array) of the mode counters of the wave tile at `base`
 __host__ __device__ inline size_t mog_count_off(int Palloc, int base)
 {
     (void)Palloc;
-    return ((size_t)(base / kWavePx) * kTileFloats + (size_t)kMogPlanes * kWavePx) * 4;
+    return (size_t)(base / kTilePx) * kTileFloats * 4 + (base % kTilePx);
 }
 #else
 __host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)kMogPlanes * Palloc; }
-__host__ __device__ inline size_t mog_plane_off(int Palloc, int plane, int base) { return (size_t)plane * Palloc + base; }
+__host__ __device__ inline size_t mog_plane_off(int Palloc, int slot, int base) { return (size_t)slot * Palloc + base; }
 __host__ __device__ inline size_t mog_plane_stride(int Palloc) { return Palloc; }
 #endif
 
@@ -88,6 +90,7 @@ struct MogParams {
     int nmix;
     int detectShadows;
     int shadowVal;
+    int restoreCount;        // MOG2Invoker's `nmodes = nNewModes;` (oatgpu_config.mog_restore_nmodes)
 };
 
 // inRange bounds after cv::inRange's normalisation: lo > hi encodes "empty".

@@ -28,6 +28,7 @@ class Config(C.Structure):
         ("v_lo", C.c_int32), ("v_hi", C.c_int32), ("erode", C.c_int32), ("dilate", C.c_int32),
         ("min_area", C.c_double), ("max_area", C.c_double),
         ("diff_threshold", C.c_int32), ("blur", C.c_int32),
+        ("mog_restore_nmodes", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ class Profile(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 2          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 3          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)

@@ -11,6 +11,19 @@
  * OpenCV is not in /root/reference; the algorithm is restated from the
  * published source.  PARITY UNPINNED by the reference.
  *
+ * Mode count.  MOG2Invoker keeps TWO counters, `int nmodes = modesUsed[x], nNewModes = nmodes;`:
+ * the prune test decrements nmodes (which also is the bound of the running mode loop and of the
+ * renormalisation loop), and right behind the renormalisation comes `nmodes = nNewModes;` -- so a
+ * pruned mode keeps its slot with weight 0 (it can still be matched, and is then revived with
+ * weight alphaT - alphaT*CT), modesUsed[x] never decreases, and a new mode replaces the LAST slot
+ * once all nmixtures slots have been used.  That is how the 2.4.x, 3.x and 4.x sources read as far
+ * as they can be recalled without a copy at hand (no OpenCV in this image nor on the GPU box:
+ * profiles/r02_opencv_probe.txt), and it is the default here (restore_nmodes = 1).  Round 1 had
+ * restated the loop without the second counter; that reading is kept as restore_nmodes = 0 so
+ * that whoever holds the 3.1.0 source can flip one switch (oracle, C ABI and kernel all take it)
+ * instead of re-deriving anything.  The two readings differ only once a weight has decayed below
+ * 2*alphaT*CT/(1-alphaT), i.e. never at Oat's default learning rate 0.
+ *
  * Build with -ffp-contract=off: the x86-64 baseline OpenCV build has no FMA,
  * so every multiply and add below rounds separately, in this order.
  */
@@ -50,6 +63,7 @@ void oat_mog2_default_params(oat_mog2_params *p)
     p->detect_shadows = 1;
     p->shadow_value = 127;
     p->tau = 0.5f;
+    p->restore_nmodes = 1;
 }
 
 oat_mog2 *oat_mog2_create(int rows, int cols, int channels, const oat_mog2_params *p)
@@ -149,7 +163,7 @@ static void mog2_rows(oat_mog2 *m, const uint8_t *image, uint8_t *maskimg,
 
             int background = 0;
             int fitsPDF = 0;
-            int nmodes = modesUsed[x];
+            int nmodes = modesUsed[x], nNewModes = nmodes;
             float totalWeight = 0.f;
             float *mean_m = mean;
 
@@ -212,6 +226,9 @@ static void mog2_rows(oat_mog2 *m, const uint8_t *image, uint8_t *maskimg,
             totalWeight = 1.f / totalWeight;
             for (int mode = 0; mode < nmodes; mode++)
                 gmm[mode].weight *= totalWeight;
+
+            if (m->p.restore_nmodes)
+                nmodes = nNewModes;
 
             /* make a new mode if needed */
             if (!fitsPDF && alphaT > 0.f) {

@@ -46,6 +46,8 @@ typedef struct {
     int detect_shadows;   /* 1 */
     uint8_t shadow_value; /* 127 */
     float tau;            /* 0.5 */
+    int restore_nmodes;   /* 1: `nmodes = nNewModes;` after the renormalisation (see mog2.c, "mode count");
+                             0: a pruned mode leaves modesUsed */
 } oat_mog2_params;
 
 void oat_mog2_default_params(oat_mog2_params *p);

@@ -19,8 +19,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 f32 = np.float32
 
 
-def mog2_pixel_trace(pixels, rates, nmix=5):
+def mog2_pixel_trace(pixels, rates, nmix=5, restore=True):
     """One pixel, 3 channels.  pixels: list of (b,g,r); rates: learning rate per frame.
+    restore: the mode count is set back to its value at entry after the renormalisation
+    (MOG2Invoker's `nmodes = nNewModes;`, see oracle/mog2.c "Mode count"); False = pruning shrinks it.
     Returns per frame: mask, nmodes, weights, variances, means (python floats of f32)."""
     Tb, TB, Tg = f32(16), f32(0.9), f32(9)
     varInit, varMin, varMax, tau = f32(15), f32(4), f32(75), f32(0.5)
@@ -45,6 +47,7 @@ def mog2_pixel_trace(pixels, rates, nmix=5):
         fits = False
         total = f32(0)
         mode = 0
+        n_entry = nmodes
         while mode < nmodes:
             weight = f32(f32(alpha1 * w[mode]) + prune)
             swaps = 0
@@ -82,6 +85,8 @@ def mog2_pixel_trace(pixels, rates, nmix=5):
             inv = f32(f32(1) / total)
         for m in range(nmodes):
             w[m] = f32(w[m] * inv)
+        if restore:
+            nmodes = n_entry
         if not fits and alphaT > 0:
             if nmodes == nmix:
                 mode = nmix - 1
@@ -291,11 +296,23 @@ def main():
                 pix.append((0, 0, 0))
             else:
                 pix.append(tuple(int(b + rng.integers(-9, 10)) for b in base))
-        traces.append(dict(name=name, rate=rate, pixels=pix, frames=mog2_pixel_trace(pix, [rate] * len(pix))))
+        for restore in (1, 0):
+            traces.append(dict(name=name + ("" if restore else "_shrink"), rate=rate, restore=restore, pixels=pix,
+                               frames=mog2_pixel_trace(pix, [rate] * len(pix), restore=bool(restore))))
     # five live modes: cycle through 6 well separated colours with a quick learner
     cols = [(10, 10, 10), (60, 200, 30), (200, 40, 90), (250, 250, 250), (20, 120, 240), (128, 0, 128)]
     pix = [cols[(t * 5 + t // 3) % 6] for t in range(40)]
-    traces.append(dict(name="five_modes", rate=0.05, pixels=pix, frames=mog2_pixel_trace(pix, [0.05] * len(pix))))
+    for restore in (1, 0):
+        traces.append(dict(name="five_modes" + ("" if restore else "_shrink"), rate=0.05, restore=restore, pixels=pix,
+                           frames=mog2_pixel_trace(pix, [0.05] * len(pix), restore=bool(restore))))
+    # pruning: colours seen once decay below the prune threshold within a few frames at rate 0.3; coming
+    # back to them later separates the two readings of the mode count (a zero-weight slot is revived /
+    # a fresh mode with varInit is made), as does filling all five slots and replacing the last one
+    pix = [cols[0]] * 3 + [cols[1]] + [cols[0]] * 9 + [cols[1]] * 2 + [cols[2], cols[3], cols[4], cols[5]] + \
+          [cols[0]] * 8 + [cols[3], cols[1], cols[5], cols[0], cols[2]] + [cols[0]] * 6 + [cols[4]] * 3
+    for restore in (1, 0):
+        traces.append(dict(name="prune_revive" + ("" if restore else "_shrink"), rate=0.3, restore=restore, pixels=pix,
+                           frames=mog2_pixel_trace(pix, [0.3] * len(pix), restore=bool(restore))))
     json.dump(traces, open(os.path.join(HERE, "mog2_trace.json"), "w"))
     # ---- posifilt kalman traces ----
     krng = np.random.default_rng(4242)

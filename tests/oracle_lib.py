@@ -17,7 +17,8 @@ class Mog2Params(C.Structure):
                 ("var_threshold", C.c_float), ("background_ratio", C.c_float),
                 ("var_threshold_gen", C.c_float), ("var_init", C.c_float),
                 ("var_min", C.c_float), ("var_max", C.c_float), ("ct", C.c_float),
-                ("detect_shadows", C.c_int), ("shadow_value", C.c_uint8), ("tau", C.c_float)]
+                ("detect_shadows", C.c_int), ("shadow_value", C.c_uint8), ("tau", C.c_float),
+                ("restore_nmodes", C.c_int)]
 
 
 class HsvParams(C.Structure):

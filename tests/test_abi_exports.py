@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_default_config(lib):
     from oat_amd import ffi
-    assert lib.oatgpu_abi_version() == 2
+    assert lib.oatgpu_abi_version() == ffi.ABI_VERSION == 3
     cfg = ffi.Config()
     assert lib.oatgpu_default_config(C.byref(cfg)) == 0
     # cv::createBackgroundSubtractorMOG2() defaults + HSVDetector.h:77-94
@@ -44,6 +44,7 @@ def test_abi_version_and_default_config(lib):
     assert abs(cfg.background_ratio - 0.9) < 1e-7 and abs(cfg.ct - 0.05) < 1e-8 and cfg.tau == 0.5
     assert (cfg.h_lo, cfg.h_hi, cfg.s_lo, cfg.s_hi, cfg.v_lo, cfg.v_hi) == (0, 256, 0, 256, 0, 256)
     assert (cfg.erode, cfg.dilate, cfg.min_area) == (0, 10, 0.0) and cfg.max_area > 1e308
+    assert cfg.mog_restore_nmodes == 1          # MOG2Invoker: nmodes = nNewModes
 
 
 def test_struct_sizes_match_the_header(lib, tmp_path):

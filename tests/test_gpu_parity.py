@@ -69,11 +69,14 @@ def test_bgr2hsv_known_answers(A, golden_dir):
 
 @pytest.mark.parametrize("shape", [(48, 64), (37, 101), (5, 3), (1, 1), (33, 256)])
 @pytest.mark.parametrize("rate", [0.0, 0.01, 0.3])
-def test_mog2_mask_and_model_parity(A, shape, rate):
+@pytest.mark.parametrize("restore", [1, 0])
+def test_mog2_mask_and_model_parity(A, shape, rate, restore):
+    """restore = 1: MOG2Invoker's `nmodes = nNewModes;` (the default); 0: pruning shrinks the mode count
+    (oracle/mog2.c "Mode count").  Masks and the full fp32 model, both readings."""
     rows, cols = shape
     rng = np.random.default_rng(rows * 1000 + cols + int(rate * 100))
-    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=rate)
-    o = O.Mog2(rows, cols, 3)
+    g = A.BackgroundSubtractorMOG(rows, cols, adaptation_coeff=rate, mog_restore_nmodes=restore)
+    o = O.Mog2(rows, cols, 3, params=dict(restore_nmodes=restore))
     base = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
     alt = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
     for t in range(120):
@@ -94,7 +97,7 @@ def test_mog2_mask_and_model_parity(A, shape, rate):
 def test_mog2_single_pixel_traces(A, golden_dir):
     """The hand-independent float32 traces of tests/golden/mog2_trace.json, on the GPU."""
     for tr in json.load(open(os.path.join(golden_dir, "mog2_trace.json"))):
-        g = A.BackgroundSubtractorMOG(1, 1)
+        g = A.BackgroundSubtractorMOG(1, 1, mog_restore_nmodes=tr.get("restore", 1))
         for t, (px, want) in enumerate(zip(tr["pixels"], tr["frames"])):
             mask = g.apply(np.array(px, np.uint8).reshape(1, 1, 3), learning_rate=tr["rate"])
             nm, w, v, mu, _ = g.mog_state()
@@ -866,3 +869,76 @@ def test_track_sequence_equals_frame_by_frame(A):
     with pytest.raises(A.OatGpuError):
         a.track_sequence_dev([bufs[1].data_ptr()])          # results outstanding
     a.collect()
+
+
+# ------------------------------------------- BASELINE configs 3 and 4 (batched) --
+
+@pytest.mark.parametrize("n", [16, 8])
+def test_hot_path_batched_1080p(A, n):
+    """BASELINE configs[2] (16 x 1080p batched on one GPU) and the per-GPU shard of configs[3]
+    (8 x 1080p): ONE context, one launch per stage for all streams, every stream against its OWN
+    oracle instance.  The discs differ per stream (count, radius, path), so a stream mix-up inside
+    the batched kernels cannot pass.  Masks, contour sums, centroids and the full fp32 model."""
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols = 1080, 1920
+    win = disc_hsv_window()
+    hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=0.01, erode=3, dilate=7, area=(20.0, 1e5), **win)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    streams = [SyntheticStream(rows, cols, 100 + s, n_discs=1 + s % 3, radius=14 + 3 * s) for s in range(n)]
+    oracles = _chain_oracles(rows, cols, n)
+    seen = set()
+    for t in range(3):
+        frames = [st.frame(t, with_discs=(t > 0)) for st in streams]
+        got = hp.track(frames)
+        for s in range(n):
+            want, thr = O.chain_step(oracles[s], frames[s], 0.01, p, nthreads=8)
+            assert (hp.read_mask(1, s) == thr).all(), (t, s)
+            _same_detection(got[s], want, (t, s))
+            if want["valid"]:
+                seen.add((want["a00"], want["a10"], want["a01"]))
+    assert len(seen) >= n                   # the streams really do give different answers
+    for s in range(n):
+        _same_state(hp.mog_state(s), oracles[s].state(), s)
+    hp.close()
+
+
+def test_measurement_env_is_inert_in_the_product_library(A):
+    """OATGPU_EXPT=1 used to make the shipped library skip the whole back half
+    and still return OATGPU_OK.  The product build no longer reads any OATGPU_* measurement switch:
+    a child process with all of them set must produce the same positions as the oracle."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, json
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+import oat_amd
+from oat_amd.synth import SyntheticStream, disc_hsv_window
+st = SyntheticStream(120, 200, 3, n_discs=1, radius=9)
+hp = oat_amd.HotPath(120, 200, n_streams=1, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+out = []
+for t in range(5):
+    r = hp.track([st.frame(t, with_discs=t > 0)])[0]
+    out.append([int(r.position_valid), r.a00, r.a10, r.a01, r.first_pixel])
+print(json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OATGPU_EXPT="1", OATGPU_SERIAL="1", OATGPU_NB="1", OATGPU_GRAPH="1",
+               OATGPU_PRIVATE_STREAMS="1", OATGPU_COPY_PAD="2")
+    env.pop("OATGPU_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    from oat_amd.synth import SyntheticStream
+    st = SyntheticStream(120, 200, 3, n_discs=1, radius=9)
+    orc = O.Mog2(120, 200, 3)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5,
+                     min_area=5.0, max_area=1e5)
+    nvalid = 0
+    for t in range(5):
+        want, _ = O.chain_step(orc, st.frame(t, with_discs=t > 0), 0.01, p)
+        assert got[t][0] == int(want["valid"]), (t, got[t], want)
+        if want["valid"]:
+            assert got[t][1:] == [want["a00"], want["a10"], want["a01"], want["first_pixel"]], (t, got[t], want)
+            nvalid += 1
+    assert nvalid >= 3

@@ -93,8 +93,10 @@ def test_contour_list_order_is_reverse_discovery():
 
 
 def test_mog2_single_pixel_traces(golden_dir):
+    names = set()
     for tr in _load(golden_dir, "mog2_trace.json"):
-        m = O.Mog2(1, 1, 3)
+        names.add(tr["name"])
+        m = O.Mog2(1, 1, 3, params=dict(restore_nmodes=tr.get("restore", 1)))
         for t, (px, want) in enumerate(zip(tr["pixels"], tr["frames"])):
             mask = m.apply(np.array(px, np.uint8).reshape(1, 1, 3), tr["rate"])
             nm, w, v, mu = m.state()
@@ -104,6 +106,35 @@ def test_mog2_single_pixel_traces(golden_dir):
             assert w[0, :k].tolist() == [np.float32(x) for x in want["weight"]], (tr["name"], t)
             assert v[0, :k].tolist() == [np.float32(x) for x in want["variance"]], (tr["name"], t)
             assert mu[0, :k].tolist() == [[np.float32(c) for c in r] for r in want["mean"]], (tr["name"], t)
+    # both readings of the mode count (oracle/mog2.c "Mode count") are pinned by their own traces
+    assert {"prune_revive", "prune_revive_shrink", "alpha05", "alpha05_shrink"} <= names
+
+
+def test_mog2_mode_count_readings_differ_only_after_a_prune():
+    """restore_nmodes = 1 (MOG2Invoker's `nmodes = nNewModes;`): modesUsed never decreases and a pruned
+    slot keeps weight 0; restore_nmodes = 0: the count shrinks.  Before the first prune the two readings
+    are the same computation."""
+    rng = np.random.default_rng(11)
+    a, b = O.Mog2(6, 7, 3), O.Mog2(6, 7, 3, params=dict(restore_nmodes=0))
+    prev = np.zeros(42, np.uint8)
+    differed = False
+    for t in range(40):
+        f = rng.integers(0, 256, (6, 7, 3), dtype=np.uint8) if t % 3 == 0 else np.full((6, 7, 3), 100, np.uint8)
+        ma, mb = a.apply(f, 0.3), b.apply(f, 0.3)
+        nma, wa, _, _ = a.state()
+        nmb, wb, _, _ = b.state()
+        assert (nma >= prev).all()                       # never shrinks
+        assert (nma >= nmb).all()
+        prev = nma
+        if not differed and (nma != nmb).any():
+            differed = True
+            # the pruned mode is still counted, with weight exactly 0 (in ITS slot: the loop ends at the
+            # prune, so slots behind it keep their stale weights and the zero need not be the last one)
+            p = int(np.flatnonzero(nma != nmb)[0])
+            assert wa[p, :nma[p]].min() == 0.0 and wb[p, :nmb[p]].min() >= 0.0
+        if not differed:
+            assert (ma == mb).all() and (wa == wb).all()
+    assert differed
 
 
 def test_mog2_frame1_and_frozen_model():
