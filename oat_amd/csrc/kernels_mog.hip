@@ -274,18 +274,20 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     for (int k = 0; k < kMaxMix; ++k) { pm.w[k] = 0.f; pm.v[k] = 0.f; pm.m[k][0] = 0.f; pm.m[k][1] = 0.f; pm.m[k][2] = 0.f; }
     int cnt = 0;
     int b = 0, gg = 0, r = 0;
-    if (active) {
-        if (!a.fresh) {
-            cnt = *nm;
-            pm.w[0] = ld_plane(st + (size_t)slot_w(0) * PS);
-            pm.v[0] = ld_plane(st + (size_t)slot_v(0) * PS);
+    // (no `active` guard: the planes are allocated for Palloc pixels, a multiple of the block's 256)
+    if (!a.fresh) {
+        cnt = *nm;
+        pm.w[0] = ld_plane(st + (size_t)slot_w(0) * PS);
+        pm.v[0] = ld_plane(st + (size_t)slot_v(0) * PS);
 #pragma unroll
-            for (int c = 0; c < CH; ++c) pm.m[0][c] = ld_plane(st + (size_t)slot_m(0, c) * PS);
-        }
-        if (valid) {
-            b = frame[fi];
-            if (CH == 3) { gg = frame[fi + 1]; r = frame[fi + 2]; }
-        }
+        for (int c = 0; c < CH; ++c) pm.m[0][c] = ld_plane(st + (size_t)slot_m(0, c) * PS);
+    }
+    // no branch around the pixel loads either (lanes beyond the image read pixel 0 and ignore it): inside
+    // a branch hipcc unpacks the bytes right there, i.e. waits for ALL phase-1 loads before the table build
+    {
+        const size_t fj = valid ? fi : 0;
+        b = frame[fj];
+        if (CH == 3) { gg = frame[fj + 1]; r = frame[fj + 2]; }
     }
 
     // The HSV tables are built (fp32 quotients, LDS, one barrier) AFTER the loads have been
@@ -323,6 +325,14 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
             for (int c = 0; c < CH; ++c) pm.m[k][c] = ld_plane(st + (size_t)slot_m(k, c) * PS);
         }
     }
+
+    // Pin the completion of the phase-2 loads HERE, on every control-flow path: hipcc counts VMEM
+    // operations conservatively across the exec-masked regions above, and without this the stores at
+    // the end each carried an `s_waitcnt vmcnt(3)` -- gfx9 counts stores in vmcnt too, so a wave never
+    // had more than four stores in flight.
+#pragma unroll
+    for (int k = 1; k < kMaxMix; ++k)
+        asm volatile("" : "+v"(pm.w[k]), "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
 
     int mask = 0, nnew = nold;
     if (valid) {
