@@ -5,22 +5,38 @@
 
 One "step" = one frame for every camera stream a rank owns, through the whole
 fused chain (MOG2 update, setTo, BGR2HSV, inRange, erode, dilate, labelling,
-contour sums, selection, result D2H).  Input frames are synthetic, uchar3, and
-already resident in HBM when the timed region starts.  Streams are independent,
-so N > 1 shards streams over ranks with no data-path collective ("weak"
-scaling: per-GPU work fixed); rank 0 prints ONE JSON line.
+contour sums, selection, result hand-off).  Input frames are synthetic, uchar3,
+and already resident in HBM when the timed region starts.  Streams are
+independent, so N > 1 shards streams over ranks with no data-path collective
+("weak" scaling: per-GPU work fixed); rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
-    1080p1   1 x 1920x1080 stream per GPU            (configs[1], the default)
+    4k1      1 x 3840x2160 per GPU, erode 7 dilate 7 (configs[4]; the default: the config the
+             north-star roofline target is stated on)
     1080p16  16 x 1920x1080 streams batched per GPU  (configs[2]; configs[3] at N=8 is 8/GPU)
     1080p8   8 x 1920x1080 per GPU                   (configs[3] shard)
-    4k1      1 x 3840x2160 per GPU, erode 7 dilate 7 (configs[4])
+    1080p1   1 x 1920x1080 stream per GPU            (configs[1])
     vga1     1 x 640x480                             (configs[0] shape)
+
+What the one JSON line carries besides the contract's keys (N = 1 only, rank 0):
+    roofline      the dominant kernel k_mog_fused against the 8 TB/s HBM peak on the leg where its 205
+                  algorithmic B/px really move (`--dense-model` input at 4K, run inside this process):
+                  achieved / frac <= 1, traffic = PMC bytes per launch of that same leg, plus, for the
+                  benched (sparse) workload: frac_real (PMC bytes / kernel time), useful / moved B/px and
+                  the waste ratio from the kernel's own traffic audit
+    cpu_baseline  the oracle chain (a port of the reference's CPU path) on this host's cores
+    extra_workloads  1080p16 and 1080p1 measured the same way (shorter runs)
+The PMC numbers come from rocprofv3 child processes of this very run (--no-pmc to skip them).
 """
 import argparse
 import json
 import os
+import platform
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,17 +59,19 @@ WORKLOADS = {
 ALPHA = 0.01
 RESTORE = 1                     # MOG2Invoker's `nmodes = nNewModes;` (oracle/mog2.c "Mode count"); 0 = the other reading
 AREA = (20.0, 1e5)
+RING = 8
+MIN_TIMED_MS = 50.0             # below this a timed region says little: flagged in the line
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_hotpath(wl, device, ring_depth, dense=False):
+def make_hotpath(wl, device, ring_depth=RING, dense=False, n_streams=None):
     import oat_amd
     from oat_amd.synth import disc_hsv_window
     win = dict(h_thresh=(0, 256), s_thresh=(0, 256), v_thresh=(255, 256)) if dense else disc_hsv_window()
-    return oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=wl["streams"], adaptation_coeff=ALPHA,
+    return oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=n_streams or wl["streams"], adaptation_coeff=ALPHA,
                            erode=wl["erode"], dilate=wl["dilate"], area=AREA, device=device,
                            ring_depth=ring_depth, mog_restore_nmodes=RESTORE, **win)
 
@@ -64,67 +82,82 @@ def oracle_params(wl):
                         dilate=wl["dilate"], min_area=AREA[0], max_area=AREA[1])
 
 
+def oracle_mog(wl):
+    import oracle_lib as O
+    return O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
+
+
+def host_threads():
+    # the port spawns its row workers per stage (no pool): beyond ~32 threads creation cost eats the gain
+    return min(os.cpu_count() or 1, 32)
+
+
 def parity_gate(wl, device, frames_seq):
     """masks pixel-exact and centroids identical vs the oracle, on a short fresh run
-    of stream 0's frames (the oracle only CHECKS here; it is never the thing measured)."""
+    (the oracle only CHECKS here; it is never the thing measured)."""
     import oracle_lib as O
-    import oat_amd
-    from oat_amd.synth import disc_hsv_window
-    hp = oat_amd.HotPath(wl["rows"], wl["cols"], n_streams=1, adaptation_coeff=ALPHA, erode=wl["erode"],
-                         dilate=wl["dilate"], area=AREA, device=device, mog_restore_nmodes=RESTORE, **disc_hsv_window())
-    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
+    hp = make_hotpath(wl, device, ring_depth=2, n_streams=1)
+    orc = oracle_mog(wl)
     p = oracle_params(wl)
-    for t, f in enumerate(frames_seq):
-        got = hp.track([f])[0]
-        want, thr = O.chain_step(orc, f, ALPHA, p, nthreads=os.cpu_count() or 1)
-        if not (hp.read_mask(1) == thr).all():
-            return f"mask mismatch at frame {t}"
-        if got.position_valid != want["valid"]:
-            return f"valid mismatch at frame {t}"
-        if want["valid"] and (abs(got.x - want["x"]) > 1e-4 or abs(got.y - want["y"]) > 1e-4):
-            return f"centroid mismatch at frame {t}"
-    hp.close()
+    try:
+        for t, f in enumerate(frames_seq):
+            got = hp.track([f])[0]
+            want, thr = O.chain_step(orc, f, ALPHA, p, nthreads=host_threads())
+            if not (hp.read_mask(1) == thr).all():
+                return f"mask mismatch at frame {t}"
+            if got.position_valid != want["valid"]:
+                return f"valid mismatch at frame {t}"
+            if want["valid"] and (abs(got.x - want["x"]) > 1e-4 or abs(got.y - want["y"]) > 1e-4):
+                return f"centroid mismatch at frame {t}"
+    finally:
+        hp.close()
     return "ok"
 
 
-def measured_run_gate(wl, frames_of_step, got_positions, nthreads):
-    """SURVEY.md 8d 'parity gates run with every benchmark': the positions the TIMED run itself
-    produced for stream 0, step by step, against the oracle chain run over the very same frame
-    sequence (model init, warm-up, timed steps).  frames_of_step: host frames of stream 0 in run
-    order; got_positions: (step index in that order, Position2D) pairs to compare."""
+def measured_run_gate(wl, frames_of_step, got_positions, tag=""):
+    """SURVEY.md 8d 'parity gates run with every benchmark': the positions the TIMED run itself produced for
+    one camera stream, step by step, against the oracle chain run over the very same frame sequence (model
+    init, warm-up, timed steps).  frames_of_step: host frames of that stream in run order;
+    got_positions: (step index in that order, Position2D) pairs to compare."""
     import oracle_lib as O
-    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
+    orc = oracle_mog(wl)
     p = oracle_params(wl)
-    want = [O.chain_step(orc, f, ALPHA, p, nthreads=nthreads)[0] for f in frames_of_step]
+    want = [O.chain_step(orc, f, ALPHA, p, nthreads=host_threads())[0] for f in frames_of_step]
     for t, g in got_positions:
         w = want[t]
         if g.position_valid != w["valid"]:
-            return f"valid mismatch at run frame {t}"
+            return f"{tag}valid mismatch at run frame {t}"
         if w["valid"] and ((g.a00, g.a10, g.a01) != (w["a00"], w["a10"], w["a01"]) or
                            abs(g.x - w["x"]) > 1e-4 or abs(g.y - w["y"]) > 1e-4):
-            return f"centroid mismatch at run frame {t}"
+            return f"{tag}centroid mismatch at run frame {t}"
     return "ok"
 
 
-def cpu_baseline(wl, frames_seq, budget_s=12.0):
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline_one(wl, frames_seq, budget_s):
     """The oracle (a port of the reference's CPU chain) timed on this host, bounded sample."""
     import oracle_lib as O
-    # the port spawns its row workers per stage (no pool): beyond ~32 threads creation cost eats the gain
-    ncores = min(os.cpu_count() or 1, 32)
-    orc = O.Mog2(wl["rows"], wl["cols"], 3, params=dict(restore_nmodes=RESTORE))
+    ncores = host_threads()
+    orc = oracle_mog(wl)
     p = oracle_params(wl)
     O.chain_step(orc, frames_seq[0], ALPHA, p, nthreads=ncores)      # frame 1 (model init), untimed
-    n = 0
-    t0 = time.perf_counter()
+    n, t0 = 0, time.perf_counter()
     while True:
         O.chain_step(orc, frames_seq[(n + 1) % len(frames_seq)], ALPHA, p, nthreads=ncores)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 2000:
             break
-    # (a) of SURVEY.md 8d: the same chain on ONE thread, a shorter sample
-    n1 = 0
-    t1 = time.perf_counter()
+    n1, t1 = 0, time.perf_counter()       # (a) of SURVEY.md 8d: the same chain on ONE thread, a shorter sample
     while True:
         O.chain_step(orc, frames_seq[(n1 + 1) % len(frames_seq)], ALPHA, p, nthreads=1)
         n1 += 1
@@ -137,23 +170,48 @@ def cpu_baseline(wl, frames_seq, budget_s=12.0):
                 value_1thread=n1 / el1, sample_1thread=f"{n1} frames, {el1:.1f} s, 1 thread")
 
 
+def cpu_baseline(name, frames_seq):
+    """Benched workload (about 12 s) plus short samples of the other two sizes BASELINE.md section 2 asks for."""
+    out = cpu_baseline_one(WORKLOADS[name], frames_seq, 12.0)
+    out["host"] = dict(nproc=os.cpu_count(), cpu_model=cpu_model_string(),
+                       note="`cores` = threads the port used (capped at 32: it spawns its row workers per stage)")
+    from oat_amd.synth import SyntheticStream
+    others = {}
+    for other in ("vga1", "1080p1", "4k1"):
+        w = WORKLOADS[other]
+        if (w["rows"], w["cols"]) == (WORKLOADS[name]["rows"], WORKLOADS[name]["cols"]):
+            continue
+        st = SyntheticStream(w["rows"], w["cols"], 0, n_discs=2)
+        fr = [st.frame(t, with_discs=t > 0) for t in range(4)]
+        r = cpu_baseline_one(w, fr, 4.0)
+        others[other] = dict(value=r["value"], value_1thread=r["value_1thread"], unit="frames/s", cores=r["cores"],
+                             sample=r["sample"])
+    out["other_sizes"] = others
+    return out
+
+
 def make_pool_dense(rows, cols, ns, nframes, rank, dev):
-    """Worst case for the model traffic: every pixel jumps among six well separated colours, so all
-    five mixture modes stay live and every plane is read and written every frame (205 B/px real)."""
+    """The case where all 205 algorithmic B/px really move: every pixel cycles through FIVE well separated
+    colours in a fixed order (own phase per pixel).  All five mixture modes stay live with near-equal weights, the
+    mode that matches is the one matched longest ago -- the LAST slot -- so no pixel ever matches mode 0 (every
+    lane loads all 25 planes), and bubbling it to the front rewrites every plane.  nframes must be a multiple of 5
+    (the pool wraps).  The kernel's traffic audit confirms 104 B read + 101 B written per pixel."""
+    assert nframes % 5 == 0
     g = torch.Generator(device=dev)
     g.manual_seed(0xD0 + rank)
-    table = torch.tensor([[20, 30, 40], [90, 200, 60], [200, 60, 120], [240, 240, 230], [40, 130, 220], [140, 20, 150]],
+    table = torch.tensor([[20, 30, 40], [90, 200, 60], [200, 60, 120], [240, 240, 230], [40, 130, 220]],
                          device=dev, dtype=torch.int16)
+    phase = torch.randint(0, 5, (ns, rows, cols), device=dev, generator=g)
     pool = []
     for t in range(nframes):
-        idx = torch.randint(0, 6, (ns, rows, cols), device=dev, generator=g)
-        f = table[idx] + torch.randint(-5, 6, (ns, rows, cols, 3), device=dev, dtype=torch.int16, generator=g)
+        f = table[(phase + t) % 5] + torch.randint(-5, 6, (ns, rows, cols, 3), device=dev, dtype=torch.int16, generator=g)
         pool.append(f.clamp_(0, 255).to(torch.uint8).contiguous())
     return pool
 
 
 def make_pool_device(rows, cols, ns, nframes, rank, dev):
-    """[nframes] tensors of shape (ns, rows, cols, 3) uint8 on `dev`."""
+    """[nframes] tensors of shape (ns, rows, cols, 3) uint8 on `dev`: gradient + fresh +-6 noise per frame,
+    every 64th pixel flickering, two saturated discs per stream on Lissajous paths."""
     from oat_amd.synth import DISC_BGR
     g = torch.Generator(device=dev)
     g.manual_seed(0x0A7 + rank)
@@ -193,39 +251,312 @@ def make_pool_device(rows, cols, ns, nframes, rank, dev):
     return pool
 
 
+class Leg:
+    """One workload on one device: synthetic pool resident in HBM + a HotPath context; frames are consumed
+    in pool order (frame 0 initialises the models), so the frame of every step is known afterwards."""
+
+    def __init__(self, name, dev_index, rank, dense=False, pool=48, input_mode="device"):
+        self.name, self.wl, self.dense = name, WORKLOADS[name], dense
+        self.dev = torch.device("cuda", dev_index)
+        wl = self.wl
+        self.ns = wl["streams"]
+        gen = make_pool_dense if dense else make_pool_device
+        self.pool = gen(wl["rows"], wl["cols"], self.ns, pool, rank, self.dev)
+        torch.cuda.synchronize()
+        self.hp = make_hotpath(wl, dev_index, dense=dense)
+        self.step = 0                    # frames consumed so far
+        self.input_mode = input_mode
+        self.host_pool = None
+        if input_mode == "host":         # page-locked frames through the pipelined oatgpu_track_enqueue
+            self.host_pool = [[f.numpy() for f in p.cpu().pin_memory()] for p in self.pool]
+        elif input_mode == "host-sync":  # pageable frames through the synchronous oatgpu_track_batch
+            self.host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in self.pool]
+
+    def pool_index(self, step):          # step 0 = the initialisation frame
+        return 0 if step == 0 else (step % len(self.pool))
+
+    def init(self):
+        self.hp.track_dev(self.pool[0].data_ptr())
+        self.step = 1
+
+    def prepare(self, n):
+        """Argument arrays of an n-step run, built outside the timed region."""
+        import ctypes as C
+        from oat_amd import ffi
+        if self.host_pool is not None:
+            return None
+        idx = [self.pool_index(self.step + i) for i in range(n)]
+        return ((C.c_void_p * n)(*[self.pool[i].data_ptr() for i in idx]), (ffi.Position * (n * self.ns))())
+
+    def run(self, n, prepared=None, keep=False):
+        """n steps through the pipelined path; returns [n][ns] raw ffi.Position when keep."""
+        import ctypes as C
+        from oat_amd import ffi
+        hp = self.hp
+        lib, ctx, lr = hp.lib, hp.ctx, hp.learning_coeff_
+        if self.host_pool is None:
+            seq, out = prepared if prepared is not None else self.prepare(n)
+            ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev(ctx, seq, n, lr, out))
+            self.step += n
+            return out if keep else None
+        out = (ffi.Position * (n * self.ns))()
+        psz = C.sizeof(ffi.Position)
+        if self.input_mode == "host-sync":
+            for i in range(n):
+                fs = self.host_pool[self.pool_index(self.step + i)]
+                ptrs = (ffi._u8p * self.ns)(*[ffi.u8(f) for f in fs])
+                buf = (ffi.Position * self.ns).from_buffer(out, i * self.ns * psz)
+                ffi.check(lib, ctx, lib.oatgpu_track_batch(ctx, ptrs, self.ns, lr, buf))
+            self.step += n
+            return out if keep else None
+        ptrs = [(ffi._u8p * self.ns)(*[ffi.u8(f) for f in fs]) for fs in self.host_pool]
+        outstanding = got = 0
+        for i in range(n):
+            if outstanding == RING:
+                buf = (ffi.Position * self.ns).from_buffer(out, got * self.ns * psz)
+                ffi.check(lib, ctx, lib.oatgpu_track_collect(ctx, buf))
+                got += 1
+                outstanding -= 1
+            ffi.check(lib, ctx, lib.oatgpu_track_enqueue(ctx, ptrs[self.pool_index(self.step + i)], self.ns, lr))
+            outstanding += 1
+        while outstanding:
+            buf = (ffi.Position * self.ns).from_buffer(out, got * self.ns * psz)
+            ffi.check(lib, ctx, lib.oatgpu_track_collect(ctx, buf))
+            got += 1
+            outstanding -= 1
+        self.step += n
+        return out if keep else None
+
+    def close(self):
+        self.hp.close()
+        self.pool = None
+
+
+def spin_up(name, dev_index, rank, seconds):
+    """Warm the DEVICE (clocks, allocator, first-launch costs) with a scratch context of the same workload
+    before the real one runs its W warm-up steps: the driver's default run times only a few milliseconds,
+    which on a cold device measured 19 k instead of 28 k fps in round 1.  Not part of W or K."""
+    leg = Leg(name, dev_index, rank + 1000, pool=4)      # (never the dense generator: any warm device will do)
+    leg.init()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        leg.run(40)
+        n += 40
+    leg.hp.synchronize()
+    leg.close()
+    return n
+
+
+def timed_run(leg, K, W, barrier, prof_every):
+    """W warm-up steps, then EXACTLY K timed steps between barriers.  Returns elapsed seconds, the K x ns
+    positions, and the HIP-event profile of the timed steps."""
+    from oat_amd.components import Position2D
+    hp = leg.hp
+    leg.init()
+    if W:
+        leg.run(W)
+    hp.profile(prof_every)       # HIP events around K1 on every prof_every-th step of the timed region
+    hp.profile_reset()
+    prepared = leg.prepare(K)
+    barrier()
+    t0 = time.perf_counter()
+    out = leg.run(K, prepared, keep=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = hp.profile_read()
+    hp.profile(0)
+    ns = leg.ns
+    positions = [[Position2D.from_c(out[t * ns + s]) for s in range(ns)] for t in range(K)]
+    return elapsed, positions, prof
+
+
+def k1_ms(prof):
+    """HIP-event time of the K1 launch on its own stream, minus what an EMPTY event pair measures there
+    (calibrated by the library): the kernel's duration as rocprofv3 reports it."""
+    raw = prof["mog_ms"] / max(prof["steps"], 1)
+    return max(raw - prof["event_pair_ms"], 1e-6), raw
+
+
+def gates(leg, W, K, positions, check_steps):
+    """Both parity gates for this leg's run, every stream of the rank."""
+    wl = leg.wl
+    first = [leg.pool[leg.pool_index(i)][0].cpu().numpy() for i in range(4)]
+    res = parity_gate(wl, leg.dev.index, first)
+    log(f"[{leg.name}] parity gate (fresh context, 4 frames, masks + centroids):", res)
+    if res != "ok" or check_steps <= 0:
+        return res, None
+    G = min(check_steps, K)
+    order = [leg.pool_index(i) for i in range(1 + W + G)]
+    for s in range(leg.ns):
+        host = {i: leg.pool[i][s].cpu().numpy() for i in set(order)}
+        res = measured_run_gate(wl, [host[i] for i in order], [(1 + W + i, positions[i][s]) for i in range(G)],
+                                tag=f"stream {s}: ")
+        if res != "ok":
+            break
+    log(f"[{leg.name}] measured-run gate ({G} timed steps x {leg.ns} stream(s) vs oracle):", res)
+    detail = (f"fresh-context masks+centroids on 4 frames; first {G} timed steps of every one of the {leg.ns} "
+              f"stream(s) vs the oracle replayed over the run's own frame sequence: {res}")
+    return res, detail
+
+
+def audit(leg, steps=6):
+    """The kernel's own traffic count over `steps` further (untimed) steps of this leg's model."""
+    leg.hp.traffic_audit(True)
+    leg.run(steps)
+    t = leg.hp.traffic_read()
+    leg.hp.traffic_audit(False)
+    px = max(t["pixels"], 1)
+    return dict(steps=steps, pixels=t["pixels"], launches=t["launches"],
+                useful_read_B_per_px=t["lane_bytes_read"] / px, useful_write_B_per_px=t["lane_bytes_written"] / px,
+                sector32_read_B_per_px=t["sector32_bytes_read"] / px, sector32_write_B_per_px=t["sector32_bytes_written"] / px,
+                sector64_read_B_per_px=t["sector64_bytes_read"] / px, sector64_write_B_per_px=t["sector64_bytes_written"] / px)
+
+
+def mode_histogram(leg):
+    nm, w, _, _, _ = leg.hp.mog_state(0)
+    k = w.shape[1]
+    live = ((w != 0) & (np.arange(k)[None, :] < nm[:, None])).sum(1)
+    return dict(stream=0, modes_used=np.bincount(nm, minlength=6)[:6].tolist(),
+                live_modes=np.bincount(live, minlength=6)[:6].tolist(),
+                mean_modes_used=float(nm.mean()), mean_live_modes=float(live.mean()))
+
+
+# ------------------------------------------------------------------ PMC legs --
+
+def pmc_child(args):
+    """Child of a rocprofv3 --pmc pass: the plain K1-bearing loop, nothing else."""
+    torch.cuda.set_device(0)
+    leg = Leg(args.workload, 0, 0, dense=args.dense_model, pool=10 if args.dense_model else args.pool)
+    leg.init()
+    leg.run(args.warmup)
+    leg.run(args.steps)
+    leg.hp.synchronize()
+    leg.close()
+
+
+def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
+    """rocprofv3 --kernel-trace --pmc <counter> around a child of this script (counters in their own pass, as
+    MI355X_MICROARCH.md prescribes).  Returns (avg counter value in KiB per k_mog_fused dispatch over the last K
+    dispatches, avg duration us, dispatches) or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="oat_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--steps", str(K), "--warmup", str(W),
+           "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA)]
+    if dense:
+        cmd.append("--dense-model")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        db = None
+        for dp, _, fs in os.walk(tmp):
+            for f in fs:
+                if f.endswith(".db"):
+                    db = os.path.join(dp, f)
+        if r.returncode != 0 or not db:
+            log(f"pmc pass {workload} {counter}: rc={r.returncode} {r.stderr[-400:]}")
+            return None
+        con = sqlite3.connect(db)
+        rows = con.execute("select kernel_name, value, duration from counters_collection where counter_name = ? "
+                           "order by start", (counter,)).fetchall()
+        vals = [(v, d) for k, v, d in rows if "k_mog_fused" in k][-K:]
+        if not vals:
+            return None
+        return sum(v for v, _ in vals) / len(vals), sum(d for _, d in vals) / len(vals) / 1e3, len(vals)
+    except Exception as e:      # never let a profiler problem break the benchmark line
+        log(f"pmc pass {workload} {counter} failed: {e}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense):
+    """HBM bytes per k_mog_fused launch of the dense leg and of the benched workload, as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled (on gfx950 it reports
+    half the bytes of coalesced streaming reads).  `bytes_per_launch` = 2 x FETCH_SIZE + WRITE_SIZE.  The guide calls
+    other access widths and WRITE_SIZE uncalibrated and asks for a calibration on a known byte count in the
+    kernel's own access pattern: the dense pass is that -- the kernel's audit gives its read and written bytes
+    exactly -- and `bytes_per_launch_calibrated` applies the two factors found there."""
+    out = dict(method="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE: separate child passes of this very run, "
+                      "KiB units, averaged over the last 24 k_mog_fused dispatches; bytes_per_launch = 2 x FETCH_SIZE + "
+                      "WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); *_calibrated = factors fitted "
+                      "on the dense pass against the kernel's audited bytes")
+    K = 24
+    df = pmc_pass("4k1", True, "FETCH_SIZE", 12, K)
+    dw = pmc_pass("4k1", True, "WRITE_SIZE", 12, K)
+    if not df or not dw:
+        return None
+    fr = fw = None
+    if dense_audit_bytes:
+        fr = dense_audit_bytes[0] / (df[0] * 1024.0)
+        fw = dense_audit_bytes[1] / (dw[0] * 1024.0)
+    out["calibration"] = dict(fetch_factor=fr, write_factor=fw,
+                              audited_read_bytes=dense_audit_bytes[0] if dense_audit_bytes else None,
+                              audited_written_bytes=dense_audit_bytes[1] if dense_audit_bytes else None)
+
+    def entry(f, w, **kw):
+        d = dict(FETCH_SIZE_KiB=f[0], WRITE_SIZE_KiB=w[0], dispatches=f[2], avg_duration_us=f[1],
+                 bytes_per_launch=2.0 * f[0] * 1024 + w[0] * 1024, **kw)
+        if fr and fw:
+            d["bytes_per_launch_calibrated"] = fr * f[0] * 1024 + fw * w[0] * 1024
+        return d
+    out["dense"] = entry(df, dw)
+    if benched_is_dense:
+        return out
+    sf = pmc_pass(workload, False, "FETCH_SIZE", W, K)
+    sw = pmc_pass(workload, False, "WRITE_SIZE", W, K)
+    if sf and sw:
+        out["benched"] = entry(sf, sw, workload=workload, warmup=W)
+    return out
+
+
+# ------------------------------------------------------------------------ main --
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="1080p1", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="4k1", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=48, help="distinct frame sets resident in HBM")
     ap.add_argument("--input", default="device", choices=["device", "host", "host-sync"],
-                    help="device: frames resident in HBM (the headline); host: pageable host frames through "
-                         "oatgpu_track_batch, i.e. PCIe-inclusive (reported in DESIGN.md, never the headline)")
+                    help="device: frames resident in HBM (the headline); host / host-sync: PCIe-inclusive variants "
+                         "(reported in DESIGN.md, never the headline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--dense-model", action="store_true",
-                    help="diagnostic: input that keeps all 5 mixture modes live on every pixel (K1 moves the full "
-                         "205 B/px) and a threshold window nothing passes; not a BASELINE config")
+                    help="make the dense diagnostic the benched workload: input that keeps all 5 mixture modes live on "
+                         "every pixel (K1 moves the full 205 B/px) and a threshold window nothing passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--per-step-calls", action="store_true",
-                    help="drive the pipelined path with one enqueue and one collect call per step from Python "
-                         "instead of one oatgpu_track_sequence_dev call for the whole run")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--no-dense-leg", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (1080p16, 1080p1)")
+    ap.add_argument("--no-spin-up", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="= --no-pmc --no-extra --no-cpu-baseline (kernel A/B runs)")
     ap.add_argument("--check-steps", type=int, default=64,
-                    help="timed steps of stream 0 replayed through the oracle after the run (0 = off)")
+                    help="timed steps of every stream replayed through the oracle after the run (0 = off)")
     ap.add_argument("--learning-rate", type=float, default=None,
                     help="MOG2 adaptation coefficient (default 0.01 = SURVEY 8d; 0 = Oat's default, frozen model)")
     ap.add_argument("--mog-restore-nmodes", type=int, default=1, choices=[0, 1],
                     help="1 (default): MOG2Invoker's `nmodes = nNewModes;` -- pruned modes keep their slot; 0: pruning "
                          "shrinks the mode count (round 1's reading); oracle/mog2.c 'Mode count'")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     global ALPHA, RESTORE
     RESTORE = args.mog_restore_nmodes
     if args.learning_rate is not None:
         ALPHA = args.learning_rate
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.quick:
+        args.no_pmc = args.no_extra = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -244,179 +575,141 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
+    solo = world == 1
 
     wl = WORKLOADS[args.workload]
     rows, cols, ns = wl["rows"], wl["cols"], wl["streams"]
     K, W = args.steps, args.warmup
-    ring = 8
+    t_start = time.perf_counter()
 
-    # ---- synthetic input pool, generated on the device once (this rank's streams have global
-    # ids rank*ns ..): gradient + fresh +-6 noise per frame, every 64th pixel flickering, two
-    # saturated discs per stream on Lissajous paths.  The pool is long enough that
-    # a disc revisits a pixel too rarely to be learnt as background.
-    pool = (make_pool_dense if args.dense_model else make_pool_device)(rows, cols, ns, args.pool, rank, dev)
-    torch.cuda.synchronize()
-    pool_host = [p[0:1].cpu().numpy() for p in pool[:8]]     # stream 0, for the parity gate / CPU baseline
+    spin_steps = 0
+    if not args.no_spin_up:
+        spin_steps = spin_up(args.workload, local_rank, rank, 0.35)
 
-    hp = make_hotpath(wl, local_rank, ring, dense=args.dense_model)
+    leg = Leg(args.workload, local_rank, rank, dense=args.dense_model, pool=10 if args.dense_model else args.pool,
+              input_mode=args.input)
 
     def barrier():
-        hp.synchronize()
+        leg.hp.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    positions = []
-    raw_results = []
+    elapsed, positions, prof = timed_run(leg, K, W, barrier, prof_every=8 if K >= 64 else 1)
+    n_found_local = sum(p.position_valid for r in positions for p in r)
 
-    host_pool = None
-    if args.input in ("host", "host-sync"):
-        # PCIe-inclusive variants (never the headline value): "host" = page-locked frames through the
-        # pipelined oatgpu_track_enqueue (copies overlap compute), "host-sync" = pageable frames
-        # through the synchronous oatgpu_track_batch (what a one-frame-at-a-time caller gets)
-        if args.input == "host":
-            host_pool = [[f.numpy() for f in p.cpu().pin_memory()] for p in pool]
-        else:
-            host_pool = [[np.ascontiguousarray(f) for f in p.cpu().numpy()] for p in pool]
+    parity, parity_detail = "skipped", None
+    if rank == 0 and not args.no_parity and not args.dense_model and args.input == "device":
+        parity, parity_detail = gates(leg, W, K, positions, args.check_steps)
 
-    prepared, sequence_out = {}, []
-
-    def prepare(nsteps):
-        import ctypes as C
-        from oat_amd import ffi
-        if host_pool is None and not args.per_step_calls:
-            prepared[nsteps] = ((C.c_void_p * nsteps)(*[pool[(i + 1) % len(pool)].data_ptr() for i in range(nsteps)]),
-                                (ffi.Position * (nsteps * ns))())
-
-    def run(nsteps, keep=False):
-        if host_pool is not None and args.input == "host-sync":
-            for i in range(nsteps):
-                r = hp.track(host_pool[(i + 1) % len(host_pool)])
-                if keep:
-                    positions.append(r)
-            return
-        import ctypes as C
-        from oat_amd import ffi
-        lib, ctx, lr = hp.lib, hp.ctx, hp.learning_coeff_
-        if host_pool is None and not args.per_step_calls:
-            # Device-resident frames: the whole sequence through oatgpu_track_sequence_dev, i.e. the
-            # enqueue/collect loop inside the library -- at ~35 us per step two Python->C calls per step
-            # are a measurable part of it (--per-step-calls times them from Python instead).  The
-            # argument arrays are built by prepare() outside the timed region.
-            seq, out = prepared.pop(nsteps)
-            ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev(ctx, seq, nsteps, lr, out))
-            if keep:
-                sequence_out.append((out, nsteps))
-            return
-        # Thin loop straight on the C ABI; the raw result records are kept and converted after the
-        # timed region (a dataclass per position would be a measurable part of a step).
-        enq, col = lib.oatgpu_track_enqueue_dev, lib.oatgpu_track_collect
-        if host_pool is not None:
-            enq_h = lib.oatgpu_track_enqueue
-            ptrs = [(ffi._u8p * ns)(*[ffi.u8(f) for f in fs]) for fs in host_pool]
-            enq = lambda ctx_, p_, lr_: enq_h(ctx_, p_, ns, lr_)
-        else:
-            ptrs = [C.c_void_p(p.data_ptr()) for p in pool]
-        npool = len(ptrs)
-        bufs = [(ffi.Position * ns)() for _ in range(nsteps)] if keep else [(ffi.Position * ns)()]
-        outstanding = got = 0
-        for i in range(nsteps):
-            if outstanding == ring:
-                ffi.check(lib, ctx, col(ctx, bufs[got if keep else 0]))
-                got += 1
-                outstanding -= 1
-            ffi.check(lib, ctx, enq(ctx, ptrs[(i + 1) % npool], lr))
-            outstanding += 1
-        while outstanding:
-            ffi.check(lib, ctx, col(ctx, bufs[got if keep else 0]))
-            got += 1
-            outstanding -= 1
-        if keep:
-            raw_results.extend(bufs)
-
-    # frame 1 initialises the models with the disc-free frame, then warm-up
-    hp.track_dev(pool[0].data_ptr())
-    prepare(W)
-    run(W)
-    hp.profile(16)           # HIP events around K1 on every 16th step of the timed region
-    hp.profile_reset()
-    prepare(K)
-    barrier()
-    t0 = time.perf_counter()
-    run(K, keep=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = hp.profile_read()
-    hp.profile(0)
-    from oat_amd.components import Position2D
-    positions.extend([Position2D.from_c(p) for p in buf] for buf in raw_results)
-    for out, nsteps in sequence_out:
-        positions.extend([Position2D.from_c(out[t * ns + s_]) for s_ in range(ns)] for t in range(nsteps))
-
-    # parity gate on this run's own frames -- after the timed region, with fresh
-    # contexts, so that it cannot disturb the measurement
-    parity = "skipped"
-    parity_detail = None
-    if rank == 0 and not args.no_parity and not args.dense_model:
-        parity = parity_gate(wl, local_rank, [p[0] for p in pool_host[:4]])
-        log("parity gate:", parity)
-        if parity == "ok" and args.check_steps > 0:
-            # the timed run's own output: model init frame, W warm-up frames, then the first
-            # check_steps timed frames of stream 0, replayed through the oracle
-            G = min(args.check_steps, K)
-            s0 = [p[0].cpu().numpy() for p in pool]                  # stream 0 of every pool frame
-            order = [0] + [(i + 1) % len(pool) for i in range(W)] + [(i + 1) % len(pool) for i in range(G)]
-            parity = measured_run_gate(wl, [s0[i] for i in order], [(1 + W + i, positions[i][0]) for i in range(G)],
-                                       min(os.cpu_count() or 1, 32))
-            log(f"measured-run gate ({G} timed steps of stream 0 vs oracle):", parity)
-            parity_detail = f"fresh-context masks+centroids on 4 frames; first {G} timed steps of stream 0 vs the oracle: {parity}"
-
-    # achievable HBM rates of this very device (plain streaming kernels), rank 0 only, after the timed region
+    # the kernel's own traffic count and the model's mode histogram, continuing this run's model
+    aud = hist = None
     hbm_read = hbm_copy = None
-    if rank == 0:
+    if rank == 0 and args.input == "device":
         try:
-            hbm_read, hbm_copy = hp.measure_hbm(1 << 30, 5)
-        except Exception as e:          # never let the probe break the benchmark line
-            log("hbm probe failed:", e)
+            aud = audit(leg)
+            hist = mode_histogram(leg)
+            hbm_read, hbm_copy = leg.hp.measure_hbm(1 << 30, 5)
+        except Exception as e:          # never let a probe break the benchmark line
+            log("audit / histogram / hbm probe failed:", e)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        found = torch.tensor([sum(p.position_valid for r in positions for p in r)], dtype=torch.int64, device=red_dev)
+        found = torch.tensor([n_found_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(found, op=dist.ReduceOp.SUM)
         n_found = int(found.item())
     else:
-        n_found = sum(p.position_valid for r in positions for p in r)
+        n_found = n_found_local
 
     if rank != 0:
         if world > 1:
+            dist.barrier()              # rank 0 prints before everybody leaves
             dist.destroy_process_group()
         return
-
-    # real HBM bytes per K1 launch from the committed PMC passes (profiles/collect_pmc.sh writes
-    # the file; the counters cannot be read from inside this process)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            tj = json.load(f)
-        if args.dense_model:        # the calibration pass of collect_pmc.sh IS the dense 4K run
-            cal = tj.get("_calibration", {})
-            if args.workload == "4k1" and cal:
-                traffic = cal["fetch_factor"] * cal["FETCH_SIZE_KiB"] * 1024 + cal["WRITE_SIZE_KiB"] * 1024
-        else:
-            traffic = tj.get(args.workload, {}).get("k_mog_fused_bytes_per_launch")
-    except Exception:
-        traffic = None
 
     total_streams = ns * world
     fps = total_streams * K / elapsed
     px_per_launch = rows * cols * ns
-    # HIP-event time of the K1 launch on its own stream, minus what an EMPTY event pair measures
-    # there (calibrated by the library): that is the kernel's duration as rocprofv3 reports it.
-    mog_ms_raw = prof["mog_ms"] / max(prof["steps"], 1)
-    mog_ms = max(mog_ms_raw - prof["event_pair_ms"], 1e-6)
-    achieved = BYTES_PER_PIXEL * px_per_launch / (mog_ms * 1e-3) / 1e9 if mog_ms > 0 else 0.0
+    mog_ms, mog_ms_raw = k1_ms(prof)
+    pool_host0 = [leg.pool[leg.pool_index(i)][0].cpu().numpy() for i in range(8)]
+    benched = dict(workload=args.workload + (" --dense-model" if args.dense_model else ""), avg_launch_ms=mog_ms,
+                   avg_launch_ms_raw_events=mog_ms_raw, empty_event_pair_ms=prof["event_pair_ms"],
+                   px_per_launch=px_per_launch,
+                   algorithmic_rate_GBps=BYTES_PER_PIXEL * px_per_launch / (mog_ms * 1e-3) / 1e9,
+                   note="algorithmic_rate = 205 B/px / kernel time; on sparse models it exceeds the pin rate because the "
+                        "kernel moves only what the arithmetic can depend on -- it is NOT a roofline fraction")
+    if aud:
+        benched.update(useful_bytes_per_px=aud["useful_read_B_per_px"] + aud["useful_write_B_per_px"],
+                       requested_sector32_bytes_per_px=aud["sector32_read_B_per_px"] + aud["sector32_write_B_per_px"],
+                       requested_sector64_bytes_per_px=aud["sector64_read_B_per_px"] + aud["sector64_write_B_per_px"],
+                       audit=aud, mode_histogram=hist)
+    leg.close()
+    del leg
+    torch.cuda.empty_cache()
+
+    # ---- the leg where the algorithmic bytes really move: 4K, all five modes live on every pixel ----
+    dense = None
+    if solo and not args.no_dense_leg and args.input == "device":
+        try:
+            if args.dense_model and args.workload == "4k1":
+                dense = dict(avg_launch_ms=mog_ms, px_per_launch=px_per_launch, steps=K, audit=aud)
+            else:
+                dl = Leg("4k1", local_rank, rank, dense=True, pool=10)
+                d_el, _, d_prof = timed_run(dl, 120, 20, lambda: (dl.hp.synchronize(), torch.cuda.synchronize()), 1)
+                d_aud = audit(dl, 4)
+                dense = dict(avg_launch_ms=k1_ms(d_prof)[0], px_per_launch=3840 * 2160, steps=120,
+                             ms_per_step=d_el / 120 * 1e3, audit=d_aud)
+                dl.close()
+                del dl
+                torch.cuda.empty_cache()
+        except Exception as e:
+            log("dense leg failed:", e)
+
+    pmc = None
+    if solo and dense and not args.no_pmc and args.input == "device":
+        t0 = time.perf_counter()
+        da = dense.get("audit")
+        aud_bytes = ((da["sector32_read_B_per_px"] * dense["px_per_launch"],
+                      da["sector32_write_B_per_px"] * dense["px_per_launch"]) if da else None)
+        pmc = pmc_traffic(args.workload, W, aud_bytes, args.dense_model)
+        log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
+
+    roofline = {"bound": "hbm", "kernel": "k_mog_fused", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "measured_stream_read_GBps": hbm_read, "measured_stream_copy_GBps": hbm_copy}
+    if dense:
+        a_dense = BYTES_PER_PIXEL * dense["px_per_launch"] / (dense["avg_launch_ms"] * 1e-3) / 1e9
+        d_tr = (pmc or {}).get("dense", {}).get("bytes_per_launch")
+        da = dense.get("audit") or {}
+        d_req = (da.get("sector32_read_B_per_px", 0) + da.get("sector32_write_B_per_px", 0)) * dense["px_per_launch"]
+        roofline.update(
+            leg="4k1 --dense-model, run inside this process: every pixel keeps five live modes and never matches the "
+                "first one, so every lane loads all 104 B/px; stores go out for planes whose bits changed (dense_audit); "
+                "HIP events on the kernel's own stream",
+            achieved=a_dense, frac=a_dense / HBM_PEAK_GBPS, frac_dense=a_dense / HBM_PEAK_GBPS,
+            bytes_per_launch=BYTES_PER_PIXEL * dense["px_per_launch"], avg_launch_ms=dense["avg_launch_ms"],
+            dense_audit=dense.get("audit"), traffic=d_tr,
+            frac_dense_traffic=(d_tr / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if d_tr else None,
+            frac_dense_requested=(d_req / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if d_req else None,
+            note="achieved = the contract's ALGORITHMIC 205 B/px / kernel time on the leg built to move them; "
+                 "frac_dense_traffic = the same launch priced at its PMC bytes, frac_dense_requested at the 32-byte "
+                 "sectors the kernel itself counted")
+    else:
+        roofline.update(leg=None, achieved=None, frac=None, traffic=None,
+                        note="dense leg not run (N > 1, --no-dense-leg or host input): no defensible fraction on this line")
+    if pmc and pmc.get("benched"):
+        b = pmc["benched"]["bytes_per_launch"]
+        benched.update(traffic=b, moved_bytes_per_px=b / px_per_launch,
+                       frac_real=b / (mog_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+        if aud:
+            benched["waste_ratio"] = benched["moved_bytes_per_px"] / max(benched["useful_bytes_per_px"], 1e-9)
+    roofline["frac_real"] = benched.get("frac_real")
+    roofline["useful_bytes_per_px"] = benched.get("useful_bytes_per_px")
+    roofline["waste_ratio"] = benched.get("waste_ratio")
+    roofline["benched_workload"] = benched
+    roofline["pmc"] = pmc
+
     line = {
         "metric": "frames/sec/GPU (1080p & 4K) mog+hsv+ccl fused; % HBM roofline",
         "value": fps,
@@ -433,17 +726,16 @@ def main():
         "config": {"workload": f"{ns} x {cols}x{rows} uchar3 stream(s) per GPU, MOG2(5 mixtures, lr {ALPHA}) + HSV + "
                                f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
                    "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
-                   "learning_rate": ALPHA, "parallelism": f"streams sharded, {world} rank(s)"},
+                   "learning_rate": ALPHA, "mog_restore_nmodes": RESTORE,
+                   "parallelism": f"streams sharded, {world} rank(s)"},
         "fps_per_gpu": fps / world,
-        "hbm_roofline_frac_whole_step": BYTES_PER_PIXEL * px_per_launch / (elapsed / K) / 1e9 / HBM_PEAK_GBPS,
-        "roofline": {"bound": "hbm", "kernel": "k_mog_fused", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "note": "achieved = ALGORITHMIC 205 B/px / K1 time; K1 skips planes of dead modes and "
-                             "unchanged planes, so real traffic (PMC) is below algorithmic and frac may exceed 1",
-                     "bytes_per_launch": BYTES_PER_PIXEL * px_per_launch, "avg_launch_ms": mog_ms,
-                     "measured_stream_read_GBps": hbm_read, "measured_stream_copy_GBps": hbm_copy,
-                     "traffic_GBps": (traffic / (mog_ms * 1e-3) / 1e9) if traffic else None,
-                     "avg_launch_ms_raw_events": mog_ms_raw, "empty_event_pair_ms": prof["event_pair_ms"]},
+        "timed_region_ms": elapsed * 1e3,
+        "timed_region_note": (None if elapsed * 1e3 >= MIN_TIMED_MS else
+                              f"timed region shorter than {MIN_TIMED_MS:.0f} ms: exactly --steps {K} were timed as the "
+                              f"contract asks, behind a {spin_steps}-step device spin-up on a scratch context and {W} "
+                              f"warm-up steps"),
+        "spin_up_steps": spin_steps,
+        "roofline": roofline,
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),
                      "gpu_total": prof["total_ms"] / max(prof["steps"], 1)},
@@ -454,12 +746,43 @@ def main():
         "input": args.input,
         "dense_model": bool(args.dense_model),
     }
-    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle meanwhile)
-        line["cpu_baseline"] = cpu_baseline(wl, [p[0] for p in pool_host])
+
+    # ---- the other BASELINE configs, same measurement, shorter runs ----
+    if solo and not args.no_extra and args.input == "device" and not args.dense_model:
+        extra = {}
+        for name, kk, ww in (("1080p16", 200, 40), ("1080p1", 1500, 100)):
+            if name == args.workload:
+                continue
+            try:
+                el_ = Leg(name, local_rank, rank, pool=24 if name == "1080p16" else 48)
+                e_el, e_pos, e_prof = timed_run(el_, kk, ww, lambda: (el_.hp.synchronize(), torch.cuda.synchronize()), 8)
+                e_par = "skipped"
+                if not args.no_parity:
+                    e_par, _ = gates(el_, ww, kk, e_pos, min(args.check_steps, 16))
+                e_aud = audit(el_, 4)
+                w_ = WORKLOADS[name]
+                ppl = w_["rows"] * w_["cols"] * w_["streams"]
+                extra[name] = dict(value=w_["streams"] * kk / e_el, unit="frames/s", steps=kk, warmup=ww,
+                                   ms_per_step=e_el / kk * 1e3, k_mog_fused_ms=k1_ms(e_prof)[0],
+                                   useful_bytes_per_px=e_aud["useful_read_B_per_px"] + e_aud["useful_write_B_per_px"],
+                                   requested_sector32_bytes_per_px=e_aud["sector32_read_B_per_px"] + e_aud["sector32_write_B_per_px"],
+                                   algorithmic_rate_GBps=BYTES_PER_PIXEL * ppl / (k1_ms(e_prof)[0] * 1e-3) / 1e9,
+                                   parity=e_par)
+                el_.close()
+                del el_
+                torch.cuda.empty_cache()
+            except Exception as e:
+                log(f"extra workload {name} failed:", e)
+        line["extra_workloads"] = extra
+
+    if not args.no_cpu_baseline and solo:          # rank 0 at N = 1 only (the other ranks would idle meanwhile)
+        line["cpu_baseline"] = cpu_baseline(args.workload, pool_host0)
     else:
         line["cpu_baseline"] = None
+    line["bench_wall_s"] = time.perf_counter() - t_start
     print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -285,6 +285,23 @@ int oatgpu_profile_enable(oatgpu_ctx *ctx, int32_t on);
 int oatgpu_profile_read(oatgpu_ctx *ctx, oatgpu_profile *out);   /* synchronises */
 int oatgpu_profile_reset(oatgpu_ctx *ctx);
 
+/* Traffic audit of the fused per-pixel kernel (measurement; bench.py's `useful_bytes_per_px`).  While on,
+ * the kernel runs in an instantiation that also counts, for every load and store it executes, the bytes its
+ * lanes ask for and the 32-byte sectors / 64-byte half lines those requests touch.  Results are unchanged
+ * (same predicates, same arithmetic); the audited launches are slower and must not be timed. */
+typedef struct oatgpu_traffic {
+    int64_t launches;                 /* audited kernel launches                          */
+    int64_t pixels;                   /* pixels processed by them                         */
+    int64_t lane_bytes_read;          /* bytes requested by the lanes: what the arithmetic */
+    int64_t lane_bytes_written;       /*   can depend on / has changed ("useful" bytes)    */
+    int64_t sector32_bytes_read;      /* the same requests in whole 32-byte sectors        */
+    int64_t sector32_bytes_written;
+    int64_t sector64_bytes_read;      /* ... and in whole 64-byte half lines               */
+    int64_t sector64_bytes_written;
+} oatgpu_traffic;
+int oatgpu_traffic_audit(oatgpu_ctx *ctx, int32_t on);             /* on != 0: zero the counters and start */
+int oatgpu_traffic_read(oatgpu_ctx *ctx, oatgpu_traffic *out);     /* synchronises */
+
 /* Achievable HBM rates of THIS device, measured with plain streaming kernels (16 B/lane, `bytes`
  * per buffer, best of `reps`): *read_gbps for a read-only sum, *copy_gbps for read+write of a copy
  * (bytes moved = 2*bytes).  The spec peak (8 TB/s on MI355X) is never reached by any kernel; these

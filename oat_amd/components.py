@@ -95,6 +95,15 @@ class _Context:
             m = _frame(mask, (self.rows, self.cols))
             self._chk(self.lib.oatgpu_set_roi_mask(self.ctx, stream, ffi.u8(m)))
 
+    def traffic_audit(self, on=True):
+        """Count what the fused per-pixel kernel loads and stores (slower launches; never time them)."""
+        self._chk(self.lib.oatgpu_traffic_audit(self.ctx, 1 if on else 0))
+
+    def traffic_read(self):
+        t = ffi.Traffic()
+        self._chk(self.lib.oatgpu_traffic_read(self.ctx, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in ffi.Traffic._fields_}
+
     def measure_hbm(self, nbytes=1 << 30, reps=5):
         """(read_GBps, copy_GBps) of plain streaming kernels on this device."""
         r, c = C.c_double(0), C.c_double(0)

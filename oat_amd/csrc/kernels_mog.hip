@@ -241,9 +241,63 @@ __device__ __forceinline__ void st_plane(float *dst, float v)
 #endif
 }
 
-template <int CH>
+// Traffic audit (oatgpu_traffic_audit): the SAME kernel with every load / store predicate also counted --
+// bytes the lanes ask for ("useful": what the arithmetic can depend on) and the 32-byte sectors / 64-byte
+// half lines those requests touch (what the memory system has to move at least).  A separate template
+// instantiation: the product kernel carries none of it.
+template <bool AUDIT>
+struct Audit {
+    unsigned lane_rd = 0, lane_wr = 0;          // bytes requested by this lane
+    unsigned s32_rd = 0, s32_wr = 0, s64_rd = 0, s64_wr = 0;   // wave totals (identical in all lanes)
+    // one 4-byte access per lane, lanes consecutive in memory: sector j = lanes 8j..8j+7
+    __device__ __forceinline__ void dword(bool m, bool wr)
+    {
+        if (!AUDIT) return;
+        const u64 bal = __ballot(m);
+        u64 b = bal; b |= b >> 4; b |= b >> 2; b |= b >> 1; b &= 0x0101010101010101ull;
+        u64 h = bal; h |= h >> 8; h |= h >> 4; h |= h >> 2; h |= h >> 1; h &= 0x0001000100010001ull;
+        const unsigned n32 = 32u * (unsigned)__popcll(b), n64 = 64u * (unsigned)__popcll(h);
+        if (wr) { lane_wr += m ? 4u : 0u; s32_wr += n32; s64_wr += n64; }
+        else { lane_rd += m ? 4u : 0u; s32_rd += n32; s64_rd += n64; }
+    }
+    // one byte per lane (the counter plane): the wave's 64 bytes are two sectors / one half line
+    __device__ __forceinline__ void byte(bool m, bool wr)
+    {
+        if (!AUDIT) return;
+        const u64 bal = __ballot(m);
+        const unsigned n32 = 32u * ((bal & 0xffffffffull ? 1u : 0u) + (bal >> 32 ? 1u : 0u)), n64 = bal ? 64u : 0u;
+        if (wr) { lane_wr += m ? 1u : 0u; s32_wr += n32; s64_wr += n64; }
+        else { lane_rd += m ? 1u : 0u; s32_rd += n32; s64_rd += n64; }
+    }
+    // nb bytes per lane of a packed run (the frame): 64*nb contiguous bytes per wave
+    __device__ __forceinline__ void run(bool m, unsigned nb, bool wr)
+    {
+        if (!AUDIT) return;
+        const unsigned lanes = (unsigned)__popcll(__ballot(m)), bytes = lanes * nb;
+        const unsigned n32 = (bytes + 31u) / 32u * 32u, n64 = (bytes + 63u) / 64u * 64u;
+        if (wr) { lane_wr += m ? nb : 0u; s32_wr += n32; s64_wr += n64; }
+        else { lane_rd += m ? nb : 0u; s32_rd += n32; s64_rd += n64; }
+    }
+    __device__ __forceinline__ void flush(unsigned long long *out, int lane, bool valid_px)
+    {
+        if (!AUDIT) return;
+        unsigned rd = lane_rd, wr = lane_wr;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { rd += __shfl_xor(rd, o); wr += __shfl_xor(wr, o); }
+        const unsigned px = (unsigned)__popcll(__ballot(valid_px));
+        if (lane == 0) {
+            atomicAdd(out + 0, (unsigned long long)px);
+            atomicAdd(out + 1, (unsigned long long)rd); atomicAdd(out + 2, (unsigned long long)wr);
+            atomicAdd(out + 3, (unsigned long long)s32_rd); atomicAdd(out + 4, (unsigned long long)s32_wr);
+            atomicAdd(out + 5, (unsigned long long)s64_rd); atomicAdd(out + 6, (unsigned long long)s64_wr);
+        }
+    }
+};
+
+template <int CH, bool AUDIT>
 __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
+    Audit<AUDIT> au;
     __shared__ int sdiv[256];
     __shared__ int hdiv[256];
 
@@ -281,6 +335,9 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
         pm.v[0] = ld_plane(st + (size_t)slot_v(0) * PS);
 #pragma unroll
         for (int c = 0; c < CH; ++c) pm.m[0][c] = ld_plane(st + (size_t)slot_m(0, c) * PS);
+        au.byte(active, false);
+#pragma unroll
+        for (int c = 0; c < 2 + CH; ++c) au.dword(active, false);
     }
     // no branch around the pixel loads either (lanes beyond the image read pixel 0 and ignore it): inside
     // a branch hipcc unpacks the bytes right there, i.e. waits for ALL phase-1 loads before the table build
@@ -288,6 +345,7 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
         const size_t fj = valid ? fi : 0;
         b = frame[fj];
         if (CH == 3) { gg = frame[fj + 1]; r = frame[fj + 2]; }
+        au.run(valid, CH, false);
     }
 
     // The HSV tables are built (fp32 quotients, LDS, one barrier) AFTER the loads have been
@@ -318,12 +376,16 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
 #pragma unroll
     for (int k = 1; k < kMaxMix; ++k) {
         const bool have = valid && k < nold;
-        if (have && ((cnt >> (kLiveShift + k)) & 1)) pm.w[k] = ld_plane(st + (size_t)slot_w(k) * PS);
+        const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
+        if (lw) pm.w[k] = ld_plane(st + (size_t)slot_w(k) * PS);
         if (have && full) {
             pm.v[k] = ld_plane(st + (size_t)slot_v(k) * PS);
 #pragma unroll
             for (int c = 0; c < CH; ++c) pm.m[k][c] = ld_plane(st + (size_t)slot_m(k, c) * PS);
         }
+        au.dword(lw, false);
+#pragma unroll
+        for (int c = 0; c < 1 + CH; ++c) au.dword(have && full, false);
     }
 
     // Pin the completion of the phase-2 loads HERE, on every control-flow path: hipcc counts VMEM
@@ -369,41 +431,50 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
         const bool was_live = k == 0 || full || ((cnt >> (kLiveShift + k)) & 1);
-        if (valid && wchg && k < nlive && was_live) st_plane(st + (size_t)slot_w(k) * PS, pm.w[k]);
-        if ((dvm >> k) & 1u) {
+        const bool sw = valid && wchg && k < nlive && was_live, svm = (dvm >> k) & 1u;
+        if (sw) st_plane(st + (size_t)slot_w(k) * PS, pm.w[k]);
+        if (svm) {
             st_plane(st + (size_t)slot_v(k) * PS, pm.v[k]);
 #pragma unroll
             for (int c = 0; c < CH; ++c) st_plane(st + (size_t)slot_m(k, c) * PS, pm.m[k][c]);
         }
+        au.dword(sw, true);
+#pragma unroll
+        for (int c = 0; c < 1 + CH; ++c) au.dword(svm, true);
         if (k >= 1 && k < nnew && pm.w[k] != 0.f) newcnt |= 1 << (kLiveShift + k);
     }
     if (newcnt != cnt || a.fresh) *nm = (uint8_t)newcnt;
+    au.byte(newcnt != cnt || a.fresh, true);
 
     if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * (g.Palloc >> 6) + (base >> 6)] = word;
+    au.run(a.thr_bits && lane == 0, 8, true);
+    au.flush(a.audit, lane, valid);
 }
 
-// ---- achievable-bandwidth probes: the simplest possible streaming kernels ----
+// ---- achievable-bandwidth probes: the best plain streaming kernels found on this chip ----
+// (tools/k1_lab.hip, profiles/r02_k1_lab.txt: one 16-byte element per thread on a FULL grid with the
+// streaming cache policy copies at 6.6 TB/s; the usual 2048-block grid-stride loop reaches 5.0)
+typedef unsigned nv4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_stream_read(const uint4 *src, size_t n, unsigned *sink)
 {
-    unsigned acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 v = src[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9e3779b9u) *sink = acc;          // keeps the loads alive, practically never taken
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const nv4 v = __builtin_nontemporal_load((const nv4 *)src + i);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) *sink = v.x;      // keeps the load alive, practically never taken
 }
 __global__ __launch_bounds__(256) void k_stream_copy(const uint4 *src, uint4 *dst, size_t n)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    __builtin_nontemporal_store(__builtin_nontemporal_load((const nv4 *)src + i), (nv4 *)dst + i);
 }
 void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)src, n16, sink);
+    hipLaunchKernelGGL(k_stream_read, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint4 *)src, n16, sink);
 }
 void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
 }
 
 __global__ void k_nop() {}
@@ -412,8 +483,13 @@ void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    if (a.channels == 1) hipLaunchKernelGGL(k_mog_fused<1>, grid, dim3(256), 0, st, g, a, first_stream);
-    else hipLaunchKernelGGL(k_mog_fused<3>, grid, dim3(256), 0, st, g, a, first_stream);
+    if (a.audit) {
+        if (a.channels == 1) hipLaunchKernelGGL((k_mog_fused<1, true>), grid, dim3(256), 0, st, g, a, first_stream);
+        else hipLaunchKernelGGL((k_mog_fused<3, true>), grid, dim3(256), 0, st, g, a, first_stream);
+    } else {
+        if (a.channels == 1) hipLaunchKernelGGL((k_mog_fused<1, false>), grid, dim3(256), 0, st, g, a, first_stream);
+        else hipLaunchKernelGGL((k_mog_fused<3, false>), grid, dim3(256), 0, st, g, a, first_stream);
+    }
 }
 
 // ------------------------------------------------------------ small kernels --

@@ -100,6 +100,11 @@ struct oatgpu_ctx {
     size_t prof_used = 0;
     oatgpu_profile prof_sum{};
     double event_pair_ms = 0.0;
+
+    // traffic audit (oatgpu_traffic_audit)
+    unsigned long long *audit_dev = nullptr;   // 8 counters
+    bool audit_on = false;
+    long long audit_launches = 0;
 };
 
 static int fail(oatgpu_ctx *c, int code, const char *fmt, ...)
@@ -277,6 +282,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bsub_bg); hipFree(c->bsub_f); hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
     hipFree(c->kal.state);
+    hipFree(c->audit_dev);
     hipFree(c->frames_ring);
     for (auto e : c->copy_ev) hipEventDestroy(e);
     for (auto &b : c->bb) {
@@ -535,6 +541,8 @@ static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rat
     a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
     a.mp = mogparams_of(c->cfg);
     a.rp = range_of(c->cfg);
+    a.audit = c->audit_on ? c->audit_dev : nullptr;
+    if (c->audit_on) c->audit_launches++;
     return a;
 }
 
@@ -1224,6 +1232,39 @@ extern "C" int oatgpu_measure_hbm(oatgpu_ctx *c, size_t bytes, int32_t reps, dou
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "bandwidth probe failed: %s", hipGetErrorString(e));
     if (read_gbps) *read_gbps = best_r;
     if (copy_gbps) *copy_gbps = best_c;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_traffic_audit(oatgpu_ctx *c, int32_t on)
+{
+    if (!c) return OATGPU_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = quiesce(c);
+    if (rc) return rc;
+    if (on) {
+        if (!c->audit_dev) HIPCHK(c, hipMalloc((void **)&c->audit_dev, 8 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->audit_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->audit_launches = 0;
+    }
+    c->audit_on = on != 0;
+    return OATGPU_OK;
+}
+extern "C" int oatgpu_traffic_read(oatgpu_ctx *c, oatgpu_traffic *out)
+{
+    if (!c || !out) return OATGPU_E_INVALID;
+    memset(out, 0, sizeof *out);
+    if (!c->audit_dev) return OATGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = quiesce(c);
+    if (rc) return rc;
+    unsigned long long h[8];
+    HIPCHK(c, hipMemcpy(h, c->audit_dev, sizeof h, hipMemcpyDeviceToHost));
+    out->launches = c->audit_launches;
+    out->pixels = (int64_t)h[0];
+    out->lane_bytes_read = (int64_t)h[1]; out->lane_bytes_written = (int64_t)h[2];
+    out->sector32_bytes_read = (int64_t)h[3]; out->sector32_bytes_written = (int64_t)h[4];
+    out->sector64_bytes_read = (int64_t)h[5]; out->sector64_bytes_written = (int64_t)h[6];
     return OATGPU_OK;
 }
 

@@ -110,6 +110,7 @@ struct MogLaunch {
     const u64 *roi_bits;     // [n][Palloc/64] region-of-interest bits (framefilt mask fused in) or nullptr
     float alphaT, alpha1, prune;
     int fresh;               // 1: model is (re)initialised this frame -> no modes
+    unsigned long long *audit;   // nullptr, or 8 device counters: the traffic-audit instantiation runs (oatgpu_traffic_audit)
     MogParams mp;
     RangeParams rp;
 };

@@ -44,6 +44,12 @@ class Profile(C.Structure):
                 ("blob_ms", C.c_double), ("total_ms", C.c_double), ("event_pair_ms", C.c_double)]
 
 
+class Traffic(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("launches", "pixels", "lane_bytes_read", "lane_bytes_written",
+                                         "sector32_bytes_read", "sector32_bytes_written",
+                                         "sector64_bytes_read", "sector64_bytes_written")]
+
+
 E_RING_FULL = -4
 E_RING_EMPTY = -5
 ABI_VERSION = 3          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
@@ -93,6 +99,8 @@ SIGNATURES = {
     "oatgpu_profile_enable": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_profile_read": (C.c_int, [_ctx, C.POINTER(Profile)]),
     "oatgpu_profile_reset": (C.c_int, [_ctx]),
+    "oatgpu_traffic_audit": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_traffic_read": (C.c_int, [_ctx, C.POINTER(Traffic)]),
     "oatgpu_measure_hbm": (C.c_int, [_ctx, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
