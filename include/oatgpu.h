@@ -178,6 +178,15 @@ int oatgpu_set_roi_mask(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *roi_m
 int oatgpu_bsub_filter(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *frame_in, uint8_t *frame_out,
                        double alpha);
 
+/* `framefilt bsub -f FILE` (BackgroundSubtractor.cpp:63-71): the background image of stream s comes from
+ * the caller (rows*cols*channels bytes) instead of the first frame.  As in the reference it cannot adapt
+ * afterwards (its fp32 accumulator is never made): oatgpu_bsub_filter with alpha > 0 then fails. */
+int oatgpu_bsub_set_background(oatgpu_ctx *ctx, int32_t stream, const uint8_t *image);
+
+/* FrameMasker::filter (FrameMasker.cpp:71-75) as a stage of its own: out = in where the ROI of stream s
+ * (oatgpu_set_roi_mask) is non-zero, 0 elsewhere; without a ROI the frame passes unchanged.  In place allowed. */
+int oatgpu_mask_filter(oatgpu_ctx *ctx, int32_t stream, const uint8_t *in, uint8_t *out);
+
 /* Threshold::filter (`framefilt thresh`, src/framefilter/Threshold.cpp:67-81): grey conversion for BGR
  * contexts, inRange [i_min, i_max] (0..256), pixels outside are zeroed.  out may equal in. */
 int oatgpu_thresh_filter(oatgpu_ctx *ctx, const uint8_t *frame_in, uint8_t *frame_out, int32_t i_min,
@@ -241,6 +250,16 @@ int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double lea
  * until the matching oatgpu_track_collect returns. */
 int oatgpu_track_enqueue(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n, double learning_rate);
 int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
+
+/* Pipelined callers that hand over HOST frames (the batched drop-in component, host/oat_track_hip.cpp):
+ * oatgpu_track_input_consumed blocks until the frames of the most recent oatgpu_track_enqueue have been
+ * read out of the caller's buffers (H2D copies done) -- from then on the caller may release or overwrite
+ * them, i.e. post() the shared-memory SOURCEs while the device is still computing (the reference releases
+ * its source right after its memcpy, FrameFilter.cpp:73-80 / PositionDetector.cpp:78-86).
+ * oatgpu_track_ready: 1 if oatgpu_track_collect would return without blocking, 0 if the oldest outstanding
+ * result is still being computed (or nothing is outstanding), < 0 on error. */
+int oatgpu_track_input_consumed(oatgpu_ctx *ctx);
+int oatgpu_track_ready(oatgpu_ctx *ctx);
 
 /* A whole recorded sequence through the pipelined path in one call (what `oat frameserve file`
  * feeding the chain amounts to, without a host round trip per frame): frames_dev[t] = frame set t

@@ -568,6 +568,25 @@ void launch_bsub(const uint8_t *in, uint8_t *out, uint8_t *bg, float *bg_f, size
     hipLaunchKernelGGL(k_bsub, dim3(blocks), dim3(256), 0, st, in, out, bg, bg_f, n, a, b, first, learn);
 }
 
+// framefilt mask: frame.setTo(0, roi_mask == 0) (FrameMasker.cpp:71-75) with the 1-bit ROI plane
+__global__ __launch_bounds__(256) void k_apply_roi(Geom g, const uint8_t *in, uint8_t *out, int ch, const u64 *roi)
+{
+    const size_t npx = (size_t)g.H * g.W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / g.W), x = (int)(i - (size_t)y * g.W);
+        const int p = y * g.Wp + x;
+        const bool keep = (roi[p >> 6] >> (p & 63)) & 1ull;
+        for (int c = 0; c < ch; ++c) out[i * ch + c] = keep ? in[i * ch + c] : 0;
+    }
+}
+void launch_apply_roi(const Geom &g, const uint8_t *in, uint8_t *out, int channels, const u64 *roi, hipStream_t st)
+{
+    const size_t npx = (size_t)g.H * g.W;
+    int blocks = (int)((npx + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_apply_roi, dim3(blocks), dim3(256), 0, st, g, in, out, channels, roi);
+}
+
 // framefilt thresh: RGB2Gray<uchar> ((1868 B + 9617 G + 4899 R + 8192) >> 14), inRange, setTo(0)
 __global__ __launch_bounds__(256) void k_thresh_filter(const uint8_t *in, uint8_t *out, size_t npx, int ch, int lo,
                                                        int hi)

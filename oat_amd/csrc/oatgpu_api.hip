@@ -59,6 +59,7 @@ struct oatgpu_ctx {
     hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
     uint8_t *frames_ring = nullptr;  // [ring_slots][n_streams*rows*cols*channels] staging for host frames
     std::vector<hipEvent_t> copy_ev; // [ring_slots] frames of this slot have arrived
+    int last_copy_slot = -1;         // slot of the most recent oatgpu_track_enqueue (host frames)
     KalmanLaunch kal{};              // kal.state == nullptr: position filter off
     bool kal_on = false;
     unsigned kal_ticket = 0;         // ticket of the next enqueued frame
@@ -650,12 +651,54 @@ extern "C" int oatgpu_bsub_filter(oatgpu_ctx *c, int32_t s, const uint8_t *in, u
         HIPCHK(c, hipMalloc((void **)&c->bsub_bg, (size_t)c->cfg.n_streams * nb));
         HIPCHK(c, hipMalloc((void **)&c->bsub_f, (size_t)c->cfg.n_streams * nb * sizeof(float)));
     }
+    if (c->bsub_have[s] == 2 && alpha > 0.0)        // the reference's accumulateWeighted asserts on its empty fp32 image
+        return fail(c, OATGPU_E_INVALID, "a background image from a file cannot adapt (adaptation-coeff must be 0)");
     HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
     const float a = (float)alpha, b = 1 - a;              // accW_: AT a = (AT)alpha, b = 1 - a
     launch_bsub(c->aux_a, c->aux_b, c->bsub_bg + (size_t)s * nb, c->bsub_f + (size_t)s * nb, nb, a, b,
                 c->bsub_have[s] ? 0 : 1, alpha > 0.0 ? 1 : 0, c->stream);
     HIPCHK(c, hipGetLastError());
-    c->bsub_have[s] = 1;
+    if (!c->bsub_have[s]) c->bsub_have[s] = 1;
+    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_bsub_set_background(oatgpu_ctx *c, int32_t s, const uint8_t *image)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!image) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
+    const size_t nb = (size_t)c->g.H * c->g.W * c->cfg.channels;
+    if (!c->bsub_bg) {
+        HIPCHK(c, hipMalloc((void **)&c->bsub_bg, (size_t)c->cfg.n_streams * nb));
+        HIPCHK(c, hipMalloc((void **)&c->bsub_f, (size_t)c->cfg.n_streams * nb * sizeof(float)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->bsub_bg + (size_t)s * nb, image, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bsub_have[s] = 2;          // from a file: the fp32 accumulator does not exist (BackgroundSubtractor.cpp:63-71)
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_mask_filter(oatgpu_ctx *c, int32_t s, const uint8_t *in, uint8_t *out)
+{
+    int rc = check_stream_ix(c, s);
+    if (rc) return rc;
+    if (!in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = quiesce(c);
+    if (rc) return rc;
+    const size_t nb = (size_t)c->g.H * c->g.W * c->cfg.channels;
+    if (!c->roi) {                                   // no mask set: FrameMasker::filter leaves the frame alone
+        if (out != in) memcpy(out, in, nb);
+        return OATGPU_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    launch_apply_roi(c->g, c->aux_a, c->aux_b, c->cfg.channels, c->roi + (size_t)s * (c->g.Palloc >> 6), c->stream);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OATGPU_OK;
@@ -869,6 +912,7 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
     for (int s = 0; s < n; ++s)
         HIPCHK(c, hipMemcpyAsync(dst + (size_t)s * fb, frames_host[s], fb, hipMemcpyHostToDevice, c->stream_c));
     HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
+    c->last_copy_slot = slot;
     return enqueue_frames(c, dst, lr, c->copy_ev[slot]);
 }
 
@@ -977,6 +1021,25 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     c->col_total++;
     c->ring_count--;
     return OATGPU_OK;
+}
+
+extern "C" int oatgpu_track_input_consumed(oatgpu_ctx *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (c->last_copy_slot < 0) return OATGPU_OK;
+    HIPCHK(c, hipEventSynchronize(c->copy_ev[c->last_copy_slot]));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_track_ready(oatgpu_ctx *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (c->ring_count == 0) return 0;
+    const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
+    const hipError_t e = hipEventQuery(c->ring_ev[slot]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(c, OATGPU_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
 }
 
 extern "C" int oatgpu_track_sequence_dev(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,

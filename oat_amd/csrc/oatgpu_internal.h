@@ -128,6 +128,8 @@ void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, cons
 // framefilt bsub (BackgroundSubtractor.cpp:87-100) on n = rows*cols*channels bytes of one stream
 void launch_bsub(const uint8_t *in, uint8_t *out, uint8_t *bg, float *bg_f, size_t n, float a, float b, int first,
                  int learn, hipStream_t st);
+// framefilt mask (FrameMasker.cpp:71-75) with ONE stream's ROI bit plane
+void launch_apply_roi(const Geom &g, const uint8_t *in, uint8_t *out, int channels, const u64 *roi, hipStream_t st);
 // framefilt thresh (Threshold.cpp:67-81): BGR->grey (channels 3) -> inRange -> setTo(0)
 void launch_thresh_filter(const uint8_t *in, uint8_t *out, size_t npx, int channels, int lo, int hi, hipStream_t st);
 // posidet diff front end of ONE frame: bits = |frame - last| > thr (or frame != 0 when !have_last); last = frame

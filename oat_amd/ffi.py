@@ -77,6 +77,8 @@ SIGNATURES = {
     "oatgpu_set_kalman": (C.c_int, [_ctx, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     "oatgpu_set_roi_mask": (C.c_int, [_ctx, C.c_int32, _u8p]),
     "oatgpu_bsub_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
+    "oatgpu_bsub_set_background": (C.c_int, [_ctx, C.c_int32, _u8p]),
+    "oatgpu_mask_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p]),
     "oatgpu_thresh_filter": (C.c_int, [_ctx, _u8p, _u8p, C.c_int32, C.c_int32]),
     "oatgpu_mog_apply": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_mog_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
@@ -91,6 +93,8 @@ SIGNATURES = {
     "oatgpu_track_sequence_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_collect": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_track_outstanding": (C.c_int, [_ctx]),
+    "oatgpu_track_input_consumed": (C.c_int, [_ctx]),
+    "oatgpu_track_ready": (C.c_int, [_ctx]),
     "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),
     "oatgpu_mog_get_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.POINTER(C.c_int32)]),
     "oatgpu_mog_set_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.c_int32]),

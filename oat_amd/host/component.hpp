@@ -211,6 +211,68 @@ protected:
     ShmRegistration src_pin_;
 };
 
+// ---- image files for `framefilt mask -f` (FrameMasker.cpp:45-62) and `framefilt bsub -f` (BackgroundSubtractor.cpp:
+// 52-68).  The reference calls cv::imread; there is no image decoder here, so the binaries read the
+// Netpbm family -- P5/P2 (grey), P6/P3 (colour), maxval <= 255 -- which every image tool writes. ----
+struct PnmImage {
+    size_t rows{0}, cols{0};
+    int channels{0};                 // 1, or 3 in B,G,R order (what imread(.., IMREAD_COLOR) returns)
+    std::vector<uint8_t> px;
+};
+inline PnmImage read_pnm(const std::string &path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("File \"" + path + "\" could not be read.");      // FrameMasker.cpp:57
+    auto token = [&]() {
+        std::string t;
+        int ch;
+        while ((ch = in.get()) != EOF) {
+            if (ch == '#') { while ((ch = in.get()) != EOF && ch != '\n') {} continue; }
+            if (isspace(ch)) { if (!t.empty()) break; continue; }
+            t.push_back((char)ch);
+        }
+        return t;
+    };
+    const std::string magic = token();
+    if (magic != "P5" && magic != "P2" && magic != "P6" && magic != "P3")
+        throw std::runtime_error("'" + path + "' is not a PGM/PPM image (only the Netpbm formats P2, P3, P5, P6 are read here)");
+    PnmImage im;
+    im.cols = strtoul(token().c_str(), nullptr, 10);
+    im.rows = strtoul(token().c_str(), nullptr, 10);
+    const unsigned long maxval = strtoul(token().c_str(), nullptr, 10);    // consumes exactly one whitespace byte after it
+    if (!im.rows || !im.cols || maxval < 1 || maxval > 255) throw std::runtime_error("'" + path + "': unsupported PNM header");
+    im.channels = (magic == "P6" || magic == "P3") ? 3 : 1;
+    const size_t n = im.rows * im.cols * im.channels;
+    im.px.resize(n);
+    if (magic == "P5" || magic == "P6") {
+        in.read((char *)im.px.data(), (std::streamsize)n);
+        if ((size_t)in.gcount() != n) throw std::runtime_error("'" + path + "' is truncated");
+    } else {
+        for (size_t i = 0; i < n; ++i) {
+            const std::string t = token();
+            if (t.empty()) throw std::runtime_error("'" + path + "' is truncated");
+            im.px[i] = (uint8_t)strtoul(t.c_str(), nullptr, 10);
+        }
+    }
+    if (maxval != 255) for (auto &v : im.px) v = (uint8_t)((v * 255u + maxval / 2) / maxval);
+    if (im.channels == 3) for (size_t i = 0; i < n; i += 3) std::swap(im.px[i], im.px[i + 2]);    // RGB file -> BGR
+    return im;
+}
+struct GreyImage { size_t rows{0}, cols{0}; std::vector<uint8_t> px; };
+// imread(path, IMREAD_GRAYSCALE): colour files go through the same fixed-point BGR->grey as cvtColor
+// ((1868 B + 9617 G + 4899 R + 8192) >> 14, the constants of Threshold.cpp's path as well)
+inline GreyImage read_pnm_grey(const std::string &path)
+{
+    PnmImage im = read_pnm(path);
+    GreyImage g;
+    g.rows = im.rows; g.cols = im.cols;
+    if (im.channels == 1) { g.px = std::move(im.px); return g; }
+    g.px.resize(im.rows * im.cols);
+    for (size_t i = 0; i < g.px.size(); ++i)
+        g.px[i] = (uint8_t)((1868 * im.px[3 * i] + 9617 * im.px[3 * i + 1] + 4899 * im.px[3 * i + 2] + (1 << 13)) >> 14);
+    return g;
+}
+
 // ---- option parsing: "TYPE SOURCE SINK [--key value | -k value | --flag]" with the reference's
 // names (SURVEY.md 8a "Option surface"); array values are TOML literals like "[0,256]". ----
 struct Options {

@@ -49,6 +49,7 @@ class ColorConvert : public FrameFilter {
 public:
     using FrameFilter::FrameFilter;
     PixelColor color_{PIX_HSV};
+    int gpu_index_{0};
 
 protected:
     PixelColor sink_color(PixelColor in) const override
@@ -61,7 +62,7 @@ protected:
     {
         oatgpu_config cfg;
         oatgpu_default_config(&cfg);
-        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols;
+        cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols;
         gpu_.create(cfg);
     }
     // ColorConvert.cpp:101-107
@@ -83,16 +84,30 @@ class BackgroundSubtractor : public FrameFilter {
 public:
     using FrameFilter::FrameFilter;
     double alpha_{0.0};             // BackgroundSubtractor.h
+    int gpu_index_{0};
+    std::string background_file_;   // -f: PGM/PPM instead of cv::imread's formats
 
 protected:
     void configure_for(const FrameParams &p) override
     {
         oatgpu_config cfg;
         oatgpu_default_config(&cfg);
-        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
+        cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
         gpu_.create(cfg);
+        if (!background_file_.empty()) {                 // BackgroundSubtractor.cpp:63-71: imread(.., COLOR)
+            PnmImage im = read_pnm(background_file_);
+            if (im.channels == 1 && cfg.channels == 3) {    // IMREAD_COLOR turns a grey file into 3 equal channels
+                std::vector<uint8_t> c3(im.px.size() * 3);
+                for (size_t i = 0; i < im.px.size(); ++i) c3[3 * i] = c3[3 * i + 1] = c3[3 * i + 2] = im.px[i];
+                im.px.swap(c3);
+                im.channels = 3;
+            }
+            if (im.rows != p.rows || im.cols != p.cols || im.channels != cfg.channels)
+                throw std::runtime_error("background image and SOURCE frames differ in size or channels");   // cv::subtract would throw
+            gpu_.check(oatgpu_bsub_set_background(gpu_.ctx, 0, im.px.data()));
+        }
     }
-    // BackgroundSubtractor.cpp:87-100 (a -f background image needs imread and is not supported)
+    // BackgroundSubtractor.cpp:87-100
     void filter(Frame &frame) override
     {
         gpu_.check(oatgpu_bsub_filter(gpu_.ctx, 0, frame.data(), frame.data(), alpha_));
@@ -105,17 +120,49 @@ protected:
     GpuCtx gpu_;
 };
 
-class Threshold : public FrameFilter {
+// src/framefilter/FrameMasker.cpp: frame.setTo(0, roi_mask == 0); without -f the frame passes unchanged
+class FrameMasker : public FrameFilter {
 public:
     using FrameFilter::FrameFilter;
-    int i_min_{0}, i_max_{256};     // Threshold.h
+    int gpu_index_{0};
+    std::string mask_file_;
 
 protected:
     void configure_for(const FrameParams &p) override
     {
         oatgpu_config cfg;
         oatgpu_default_config(&cfg);
-        cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
+        cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
+        if (cfg.channels != 1 && cfg.channels != 3) throw std::runtime_error("framefilt mask (hip) needs 1- or 3-byte pixels");
+        gpu_.create(cfg);
+        if (!mask_file_.empty()) {
+            const GreyImage m = read_pnm_grey(mask_file_);            // FrameMasker.cpp:52-60
+            if (m.rows != p.rows || m.cols != p.cols)
+                throw std::runtime_error("Mask image and frame source image do not have equal sizes");
+            gpu_.check(oatgpu_set_roi_mask(gpu_.ctx, 0, m.px.data()));
+        }
+    }
+    void filter(Frame &frame) override { gpu_.check(oatgpu_mask_filter(gpu_.ctx, 0, frame.data(), frame.data())); }
+    bool filter_from_shm(const Frame &in, Frame &out) override
+    {
+        gpu_.check(oatgpu_mask_filter(gpu_.ctx, 0, in.data(), out.data()));
+        return true;
+    }
+    GpuCtx gpu_;
+};
+
+class Threshold : public FrameFilter {
+public:
+    using FrameFilter::FrameFilter;
+    int i_min_{0}, i_max_{256};     // Threshold.h
+    int gpu_index_{0};
+
+protected:
+    void configure_for(const FrameParams &p) override
+    {
+        oatgpu_config cfg;
+        oatgpu_default_config(&cfg);
+        cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.channels = color_bytes(p.color);
         gpu_.create(cfg);
     }
     // Threshold.cpp:67-81
@@ -135,41 +182,57 @@ static void usage()
 {
     std::cout << "Usage: oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]\n"
                  "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: BGR -> HSV colour conversion on an MI355X\n"
-                 "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n      --gpu-index          HIP device ordinal\n"
+                 "  bsub | thresh | mask: the other per-pixel filters of oat-framefilt\n"
+                 "all:  --gpu-index N           HIP device ordinal (default 0)\n"
+                 "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n"
                  "      --model-file FILE    resume the background model from FILE if it exists; checkpoint it there on exit\n"
                  "col:  -C, --color             HSV\n"
                  "bsub: -a, --adaptation-coeff  0..1, default 0 (static background = first frame)\n"
+                 "      -f, --background FILE   PGM/PPM background image instead of the first frame\n"
+                 "mask: -f, --mask FILE         PGM/PPM: pixels where it is 0 are set to 0\n"
                  "thresh: -I, --intensity       [min,max] in [0,256]\n";
 }
 
 int main(int argc, char **argv)
 {
     try {
-        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"I", "intensity"}, {"h", "help"}, {"v", "version"}}, {"help", "version"});
+        // -f is "background" for bsub and "mask" for mask (BackgroundSubtractor.cpp:52, FrameMasker.cpp:45)
+        const bool is_mask = argc > 1 && std::string(argv[1]) == "mask";
+        Options o = Options::parse(argc, argv, {{"a", "adaptation-coeff"}, {"C", "color"}, {"I", "intensity"},
+                                                {"f", is_mask ? "mask" : "background"}, {"h", "help"}, {"v", "version"}}, {"help", "version"});
         if (o.has("version")) { std::cout << "oat-framefilt-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 3) { usage(); return o.has("help") ? 0 : -1; }
         const std::string type = o.positional[0];
         // option names per TYPE: BackgroundSubtractorMOG.cpp:51-67, ColorConvert.cpp:45-63,
         // BackgroundSubtractor.cpp:42-60, Threshold.cpp:40-54
         if (type == "mog") o.apply_config({"adaptation-coeff", "gpu-index", "model-file"});
-        else if (type == "col") o.apply_config({"color"});
-        else if (type == "bsub") o.apply_config({"adaptation-coeff", "background"});
-        else if (type == "thresh") o.apply_config({"intensity"});
+        else if (type == "col") o.apply_config({"color", "gpu-index"});
+        else if (type == "bsub") o.apply_config({"adaptation-coeff", "background", "gpu-index"});
+        else if (type == "thresh") o.apply_config({"intensity", "gpu-index"});
+        else if (type == "mask") o.apply_config({"mask", "gpu-index"});
+        const int gpu_index = (int)o.num("gpu-index", 0, 0, 64);
         std::unique_ptr<Component> comp;
         if (type == "mog") {
             auto f = std::make_unique<BackgroundSubtractorMOG>(o.positional[1], o.positional[2]);
             f->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);     // BackgroundSubtractorMOG.cpp:86-88
-            f->gpu_index_ = (int)o.num("gpu-index", 0, 0, 64);
+            f->gpu_index_ = gpu_index;
             if (o.has("model-file")) f->model_file_ = o.kv["model-file"];
             comp = std::move(f);
         } else if (type == "col") {
             auto f = std::make_unique<ColorConvert>(o.positional[1], o.positional[2]);
             if (o.has("color") && o.kv["color"] != "HSV") throw std::runtime_error("only -C HSV is supported");
+            f->gpu_index_ = gpu_index;
             comp = std::move(f);
         } else if (type == "bsub") {
             auto f = std::make_unique<BackgroundSubtractor>(o.positional[1], o.positional[2]);
             f->alpha_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);                // BackgroundSubtractor.cpp:75
-            if (o.has("background")) throw std::runtime_error("--background needs an image reader: not supported");
+            if (o.has("background")) f->background_file_ = o.kv["background"];
+            f->gpu_index_ = gpu_index;
+            comp = std::move(f);
+        } else if (type == "mask") {
+            auto f = std::make_unique<FrameMasker>(o.positional[1], o.positional[2]);
+            if (o.has("mask")) f->mask_file_ = o.kv["mask"];
+            f->gpu_index_ = gpu_index;
             comp = std::move(f);
         } else if (type == "thresh") {
             auto f = std::make_unique<Threshold>(o.positional[1], o.positional[2]);
@@ -179,6 +242,7 @@ int main(int argc, char **argv)
                     throw std::runtime_error("Values of intensity should be between 0 and 256.");   // Threshold.cpp:62-63
                 f->i_min_ = (int)a; f->i_max_ = (int)b;
             }
+            f->gpu_index_ = gpu_index;
             comp = std::move(f);
         } else {
             throw std::runtime_error("Selected TYPE is invalid.");

@@ -51,7 +51,8 @@ static void usage()
     std::cout << "Usage: oat-posidet-hip TYPE SOURCE SINK [CONFIGURATION]\nTYPE\n  hsv | thresh | diff\n"
                  "diff:   -d diff-threshold (default 10)  -b blur (default 2, <= 22)  -a [min,max] area\n"
                  "hsv:    -H/-S/-V [min,max] in [0,256]  -e erode  -d dilate (default 10)  -a [min,max] area\n"
-                 "thresh: -T [min,max]  -e erode  -d dilate  -a [min,max] area\n";
+                 "thresh: -T [min,max]  -e erode  -d dilate  -a [min,max] area\n"
+                 "all:    --gpu-index N  HIP device ordinal (default 0)\n";
 }
 
 int main(int argc, char **argv)
@@ -68,12 +69,13 @@ int main(int argc, char **argv)
         const std::string type = o.positional[0];
         if (type != "hsv" && type != "thresh" && type != "diff") throw std::runtime_error("Selected TYPE is invalid.");
         // option names per TYPE: HSVDetector.cpp:49-75, SimpleThreshold.cpp:49-69, DifferenceDetector.cpp:41-62
-        if (type == "hsv") o.apply_config({"h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "tune"}, {"tune"});
-        else if (type == "thresh") o.apply_config({"thresh", "erode", "dilate", "area", "tune"}, {"tune"});
-        else o.apply_config({"diff-threshold", "blur", "area", "tune"}, {"tune"});
+        if (type == "hsv") o.apply_config({"h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "tune", "gpu-index"}, {"tune"});
+        else if (type == "thresh") o.apply_config({"thresh", "erode", "dilate", "area", "tune", "gpu-index"}, {"tune"});
+        else o.apply_config({"diff-threshold", "blur", "area", "tune", "gpu-index"}, {"tune"});
         if (o.has("tune")) throw std::runtime_error("--tune needs a GUI and is not available in the hip detector");
         auto d = std::make_unique<GpuDetector>(o.positional[1], o.positional[2],
                                                type == "hsv" ? Kind::HSV : type == "thresh" ? Kind::THRESH : Kind::DIFF);
+        d->cfg_.device = (int)o.num("gpu-index", 0, 0, 64);
         double a, b;
         auto range = [](double x, double y, const char *what) {
             if (x < 0 || x > 256 || y < 0 || y > 256) throw std::runtime_error(std::string("Values of ") + what + " should be between 0 and 256.");

@@ -1,60 +1,178 @@
-// oat-track-hip SOURCE SINK [CONFIGURATION]
-// The whole chain  framefilt mog -> framefilt col -C HSV -> posidet hsv  in ONE process and ONE
-// fused device pass per frame: BGR oat::Frame in, oat::Position2D out (one token out per token
-// in, carrying the frame's Sample -- PositionDetector.cpp:80).  Options are the union of the
-// three stock components' (-a is mog's adaptation coefficient; the detector's area is --area).
+// oat-track-hip SOURCE[,SOURCE...] SINK[,SINK...] [CONFIGURATION]
+//
+// The whole chain  framefilt mog -> framefilt col -C HSV -> posidet hsv  (optionally -> posifilt kalman)
+// for N camera streams in ONE process, ONE device context and ONE fused launch per stage and step:
+// N BGR oat::Frame SOURCEs in, N oat::Position2D SINKs out -- SOURCE i feeds SINK i, one token out per
+// token in, in order, carrying its frame's Sample (PositionDetector.cpp:80).  N = 1 is the drop-in for a
+// single pipeline; N > 1 is the reference's multi-camera shape (examples/two-gige/two-gige.sh:7-8: one
+// component instance per camera) batched into one launch, which is what BASELINE configs 3 and 4 ask for.
+//
+// The loop is the reference's (FrameFilter.cpp:59-98, PositionDetector.cpp:58-99) with its three phases
+// pipelined through the library's result ring instead of run back to back:
+//
+//   wait on every SOURCE                              PositionDetector.cpp:63-75
+//   oatgpu_track_enqueue(frames in shared memory)     the H2D copies read the (page-locked) shm frames
+//   oatgpu_track_input_consumed, post every SOURCE    the reference posts right after its memcpy (:78-86);
+//                                                     here right after the DMA out of the segment
+//   collect + publish finished results                :88-96, SINK i: wait, *shared = position, post
+//
+// A result is published as soon as it is ready when no new frame is waiting (minimum latency, camera-bound
+// pipelines), and only when the ring is full otherwise (frames waiting: copy of step t+1 overlaps the
+// kernels of step t, GPU-bound pipelines).  Options are the union of the three stock components'
+// (-a is mog's adaptation coefficient; the detector's area is --area).
 #include "component.hpp"
+#include <deque>
 #include <unistd.h>
 
 using namespace oat;
 
-class FusedTracker : public PositionDetector {
-public:
-    FusedTracker(const std::string &src, const std::string &snk) : PositionDetector(src, snk)
-    {
-        oatgpu_default_config(&cfg_);
-        required_color_ = PIX_BGR;
-        name_ = "track[" + src + "->" + snk + "]";
+static std::vector<std::string> split_list(const std::string &s)
+{
+    std::vector<std::string> out;
+    size_t a = 0;
+    while (a <= s.size()) {
+        const size_t b = s.find(',', a);
+        const std::string t = s.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        if (t.empty()) throw std::runtime_error("empty address in list '" + s + "'");
+        out.push_back(t);
+        if (b == std::string::npos) break;
+        a = b + 1;
     }
+    return out;
+}
+
+class BatchedTracker : public Component {
+public:
+    BatchedTracker(const std::vector<std::string> &sources, const std::vector<std::string> &sinks)
+        : source_addresses_(sources), sink_addresses_(sinks), n_((int)sources.size())
+    {
+        if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
+        oatgpu_default_config(&cfg_);
+        name_ = "track[" + sources[0] + (n_ > 1 ? ",..(" + std::to_string(n_) + ")" : "") + "->" + sinks[0] + (n_ > 1 ? ",.." : "") + "]";
+        frame_sources_ = std::vector<Source<Frame>>(n_);
+        position_sinks_ = std::vector<Sink<Position2D>>(n_);
+        src_pins_ = std::vector<ShmRegistration>(n_);
+    }
+    std::string name() const override { return name_; }
     oatgpu_config cfg_;
     double learning_coeff_{0.0};
     bool kalman_{false};            // --kalman: `posifilt kalman` fused behind the detector
     double dt_{0.02}, timeout_{0.0}, sig_accel_{5.0}, sig_noise_{0.0};   // KalmanFilter2D.h:56-60
-    std::string model_file_;        // --model-file: resume the MOG2 model from / checkpoint it to this file
-    ~FusedTracker() override
+    std::string model_file_;        // --model-file: resume the MOG2 model(s) from / checkpoint to this file
+    std::string mask_file_;         // --mask: `framefilt mask` fused in front of mog (FrameMasker.cpp:45-75)
+    ~BatchedTracker() override
     {
-        if (!model_file_.empty() && gpu_.ctx && oatgpu_mog_save(gpu_.ctx, 0, model_file_.c_str()) != OATGPU_OK)
-            std::cerr << name() << ": " << oatgpu_last_error(gpu_.ctx) << std::endl;
+        if (!model_file_.empty() && gpu_.ctx)
+            for (int s = 0; s < n_; ++s)
+                if (oatgpu_mog_save(gpu_.ctx, s, model_path(s).c_str()) != OATGPU_OK)
+                    std::cerr << name() << ": " << oatgpu_last_error(gpu_.ctx) << std::endl;
     }
 
 protected:
-    void configure_for(const FrameParams &p) override
+    std::string model_path(int s) const { return n_ == 1 ? model_file_ : model_file_ + "." + std::to_string(s); }
+
+    // PositionDetector.cpp:40-56, for every stream
+    bool connectToNode() override
     {
-        cfg_.rows = (int)p.rows; cfg_.cols = (int)p.cols; cfg_.n_streams = 1;
+        for (int s = 0; s < n_; ++s) frame_sources_[s].touch(source_addresses_[s]);
+        FrameParams p0{};
+        for (int s = 0; s < n_; ++s) {
+            if (frame_sources_[s].connect(PIX_BGR) != SourceState::CONNECTED) return false;
+            const FrameParams p = frame_sources_[s].parameters();
+            if (s == 0) p0 = p;
+            else if (p.rows != p0.rows || p.cols != p0.cols)
+                throw std::runtime_error("all SOURCEs of one batched tracker must have the same frame geometry");
+        }
+        cfg_.rows = (int)p0.rows; cfg_.cols = (int)p0.cols; cfg_.n_streams = n_;
+        if (cfg_.ring_depth < 2) cfg_.ring_depth = 2;
         gpu_.create(cfg_);
-        if (!model_file_.empty() && access(model_file_.c_str(), R_OK) == 0)
-            gpu_.check(oatgpu_mog_load(gpu_.ctx, 0, model_file_.c_str()));
+        if (!model_file_.empty())
+            for (int s = 0; s < n_; ++s)
+                if (access(model_path(s).c_str(), R_OK) == 0) gpu_.check(oatgpu_mog_load(gpu_.ctx, s, model_path(s).c_str()));
+        if (!mask_file_.empty()) {
+            const GreyImage m = read_pnm_grey(mask_file_);               // FrameMasker.cpp:45-62: imread(.., GRAYSCALE)
+            if (m.rows != p0.rows || m.cols != p0.cols) throw std::runtime_error("Mask image and frame source image do not have equal sizes");   // FrameMasker.cpp:77-81
+            for (int s = 0; s < n_; ++s) gpu_.check(oatgpu_set_roi_mask(gpu_.ctx, s, m.px.data()));
+        }
         if (kalman_) gpu_.check(oatgpu_set_kalman(gpu_.ctx, 1, dt_, timeout_, sig_accel_, sig_noise_));
-    }
-    bool detect_from_shm(const Frame &frame, Position2D &position) override
-    {
-        detectPosition(const_cast<Frame &>(frame), position);      // reads only
+        for (int s = 0; s < n_; ++s) {
+            position_sinks_[s].bind(sink_addresses_[s], sink_addresses_[s]);
+            shared_positions_.push_back(position_sinks_[s].retrieve());
+        }
+        frame_ptrs_.resize(n_);
+        results_.resize(n_);
         return true;
     }
-    void detectPosition(Frame &frame, Position2D &position) override
+
+    // one result set (oldest outstanding) -> the SINKs, PositionDetector.cpp:88-96
+    void publish()
     {
-        const uint8_t *f = frame.data();
-        oatgpu_position r;
-        gpu_.check(oatgpu_track_batch(gpu_.ctx, &f, 1, learning_coeff_, &r));
-        position.position_valid = r.valid != 0;
-        if (kalman_) {                                          // KalmanFilter2D.cpp:123-137
-            position.position.x = r.x; position.position.y = r.y;
-            position.velocity.x = r.vx; position.velocity.y = r.vy;
-            position.velocity_valid = r.velocity_valid != 0;
-        } else if (r.valid) {
-            position.position.x = r.x; position.position.y = r.y;
+        gpu_.check(oatgpu_track_collect(gpu_.ctx, results_.data()));
+        const std::vector<Sample> samples = std::move(pending_.front());
+        pending_.pop_front();
+        for (int s = 0; s < n_; ++s) {
+            const oatgpu_position &r = results_[s];
+            Position2D pos("");
+            pos.set_sample(samples[s]);                              // PositionDetector.cpp:80
+            pos.position_valid = r.valid != 0;
+            if (kalman_) {                                           // KalmanFilter2D.cpp:123-137
+                pos.position.x = r.x; pos.position.y = r.y;
+                pos.velocity.x = r.vx; pos.velocity.y = r.vy;
+                pos.velocity_valid = r.velocity_valid != 0;
+            } else if (r.valid) {                                    // DetectorFunc.cpp:46,58-60: x/y only when found
+                pos.position.x = r.x; pos.position.y = r.y;
+            }
+            position_sinks_[s].wait();
+            *shared_positions_[s] = pos;
+            position_sinks_[s].post();
         }
     }
+
+    int process() override
+    {
+        // ---- a frame from every camera (PositionDetector.cpp:63-75) ----
+        std::vector<Sample> samples(n_);
+        for (int s = 0; s < n_; ++s) {
+            if (frame_sources_[s].wait() == NodeState::END) {
+                for (int q = 0; q < s; ++q) frame_sources_[q].post();     // hand back what was taken this round
+                while (!pending_.empty() && !quit) publish();             // every frame already taken still gets its token
+                return 1;
+            }
+            const Frame &shm = *frame_sources_[s].retrieve();
+            src_pins_[s].pin(shm);
+            frame_ptrs_[s] = shm.data();
+            samples[s] = shm.sample();
+        }
+        gpu_.check(oatgpu_track_enqueue(gpu_.ctx, frame_ptrs_.data(), n_, learning_coeff_));
+        pending_.push_back(std::move(samples));
+        gpu_.check(oatgpu_track_input_consumed(gpu_.ctx));                // the DMA has left the segments ...
+        for (int s = 0; s < n_; ++s) frame_sources_[s].post();            // ... upstream may write the next frames
+
+        // ---- results: as early as possible when no camera has a frame waiting, otherwise when the ring is full ----
+        while (!pending_.empty() && !quit) {
+            const bool full = (int)pending_.size() == cfg_.ring_depth;
+            if (!full && frames_waiting()) break;
+            publish();
+        }
+        return 0;
+    }
+
+    bool frames_waiting()
+    {
+        for (int s = 0; s < n_; ++s) if (!frame_sources_[s].token_waiting()) return false;
+        return true;
+    }
+
+    std::string name_;
+    std::vector<std::string> source_addresses_, sink_addresses_;
+    int n_;
+    std::vector<Source<Frame>> frame_sources_;
+    std::vector<Sink<Position2D>> position_sinks_;
+    std::vector<Position2D *> shared_positions_;
+    std::vector<ShmRegistration> src_pins_;    // declared after the sources: unregistered before the segments are unmapped
+    std::vector<const uint8_t *> frame_ptrs_;
+    std::vector<oatgpu_position> results_;
+    std::deque<std::vector<Sample>> pending_;  // Samples of the frames whose results are still on the device
     GpuCtx gpu_;
 };
 
@@ -63,16 +181,19 @@ int main(int argc, char **argv)
     try {
         Options o = Options::parse(argc, argv,
             {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
-             {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"h", "help"}, {"v", "version"}}, {"help", "version", "kalman"});
+             {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"f", "mask"}, {"h", "help"}, {"v", "version"}},
+            {"help", "version", "kalman"});
         if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
-            std::cout << "Usage: oat-track-hip SOURCE SINK [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]] [--model-file FILE]\n"
-                         "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n";
+            std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
+                         "       [--gpu-index N] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
+                         "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
+                         "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise"}, {"kalman"});
-        auto t = std::make_unique<FusedTracker>(o.positional[0], o.positional[1]);
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask"}, {"kalman"});
+        auto t = std::make_unique<BatchedTracker>(split_list(o.positional[0]), split_list(o.positional[1]));
         t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
         double a, b;
         if (o.arr2("h-thresh", a, b)) { t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b; }
@@ -81,7 +202,10 @@ int main(int argc, char **argv)
         if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
         if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
         if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }
+        t->cfg_.device = (int)o.num("gpu-index", 0, 0, 64);
+        t->cfg_.ring_depth = (int)o.num("ring", 2, 1, 64);
         if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
+        if (o.has("mask")) t->mask_file_ = o.kv["mask"];
         t->kalman_ = o.has("kalman");
         t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)
         t->timeout_ = o.num("timeout", 0.0, 0, 1e18);

@@ -405,6 +405,16 @@ public:
     }
     SourceState state() const { return state_; }
     uint64_t write_number() const { return node_->write_number(); }
+    // Would wait() return at once?  (A new token has been posted for this slot, or the sink has ended.)
+    // Not in the reference: the batched tracker uses it to choose between taking the next frames and
+    // publishing a finished result first.
+    bool token_waiting()
+    {
+        if (state_ < SourceState::TOUCHED) return false;
+        int v = 0;
+        sem_getvalue(&node_->read_barrier(slot_index_), &v);
+        return v > 0 || node_->sink_state() == NodeState::END;
+    }
 
 protected:
     // Source.h:149-185 (common part of both connect()s)

@@ -217,3 +217,147 @@ sigma-noise = 1
             assert abs(g["vel_xy"][0] - k["vx"]) < 1e-4 * max(1, abs(k["vx"])), t
             assert abs(g["vel_xy"][1] - k["vy"]) < 1e-4 * max(1, abs(k["vy"])), t
     assert tracked >= n - 4
+
+
+# ------------------------------------------------- batched, pipelined tracker --
+
+def _run_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200):
+    """n feeders -> ONE oat-track-hip (n SOURCEs, n SINKs, one context, one launch per stage) -> n readers."""
+    n = len(streams_frames)
+    rows, cols = streams_frames[0][0].shape[:2]
+    tag = "oat_t_" + uuid.uuid4().hex[:8]
+    srcs = [f"{tag}raw{s}" for s in range(n)]
+    snks = [f"{tag}pos{s}" for s in range(n)]
+    B = lambda b: os.path.join(host_bins, b)
+    # (readers write to files: pipes drained one after the other would fill up and stall the pipeline)
+    files = [open(tmp_path / f"reader{s}.out", "w+") for s in range(n)]
+    readers = [subprocess.Popen([B("oat-posi-cout"), a], stdout=f, text=True) for a, f in zip(snks, files)]
+    tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
+                                "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
+                                "--ring", str(ring)] + list(extra))
+    time.sleep(3.0)
+    feeders = []
+    for s in range(n):
+        raw = tmp_path / f"frames{s}.raw"
+        np.stack(streams_frames[s]).tofile(raw)
+        feeders.append(subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", str(raw), "--rows", str(rows), "--cols",
+                                         str(cols), "-n", str(len(streams_frames[s])), "-r", str(fps)]))
+    outs = []
+    try:
+        for r, fl in zip(readers, files):
+            r.wait(timeout=240)
+            fl.seek(0)
+            outs.append([json.loads(l) for l in fl.read().splitlines() if l.strip()])
+        for f in feeders:
+            f.wait(timeout=60)
+        tracker.wait(timeout=60)
+    finally:
+        for p in readers + feeders + [tracker]:
+            if p.poll() is None:
+                p.kill()
+        subprocess.run([B("oat-clean-hip")] + srcs + snks, capture_output=True)
+    assert tracker.returncode == 0
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring", [2, 4])
+def test_batched_tracker_four_cameras_match_their_oracles(host_bins, tmp_path, ring):
+    """BASELINE configs 3/4 from the drop-in boundary.  Four cameras with different discs into
+    one batched, pipelined oat-track-hip; every stream must equal ITS oracle frame by frame, one token out per
+    token in, each carrying its own frame's Sample."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n, ncam = 240, 320, 20, 4
+    streams = [SyntheticStream(rows, cols, 20 + s, n_discs=1, radius=8 + 3 * s) for s in range(ncam)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
+    got = _run_batched(host_bins, tmp_path, frames, ring=ring)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    areas = set()
+    for s in range(ncam):
+        assert len(got[s]) == n, (s, len(got[s]))
+        orc = O.Mog2(rows, cols, 3)
+        hits = 0
+        for t, (f, g) in enumerate(zip(frames[s], got[s])):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["usec"] == (t + 1) * 5000, (s, t, g)
+            assert g["pos_ok"] == want["valid"], (s, t)
+            if want["valid"]:
+                hits += 1
+                areas.add(want["a00"])
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
+        assert hits >= n - 3, (s, hits)
+    assert len(areas) >= ncam                     # the cameras really saw different things
+
+
+def _write_pnm(path, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    if img.ndim == 2:
+        hdr = f"P5\n# written by the tests\n{img.shape[1]} {img.shape[0]}\n255\n".encode()
+        data = img.tobytes()
+    else:
+        hdr = f"P6\n{img.shape[1]} {img.shape[0]}\n255\n".encode()
+        data = img[..., ::-1].tobytes()                 # PPM is RGB
+    with open(path, "wb") as f:
+        f.write(hdr + data)
+
+
+def _grey_chain(host_bins, tmp_path, frames, filt_args, color="GREY"):
+    """frameserve -> oat-framefilt-hip <filt_args> -> oat-posidet-hip thresh -> posi-cout (GREY frames)."""
+    rows, cols = frames[0].shape[:2]
+    raw = tmp_path / "g.raw"
+    np.stack(frames).tofile(raw)
+    tag = "oat_t_" + uuid.uuid4().hex[:8]
+    a_raw, a_f, a_pos = tag + "raw", tag + "f", tag + "pos"
+    B = lambda b: os.path.join(host_bins, b)
+    reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([B("oat-posidet-hip"), "thresh", a_f, a_pos, "-T", "[100,256]", "-a", "[4,100000]"]),
+             subprocess.Popen([B("oat-framefilt-hip"), filt_args[0], a_raw, a_f] + list(filt_args[1:]))]
+    time.sleep(3.0)
+    feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols", str(cols),
+                               "-C", color, "-n", str(len(frames)), "-r", "200"])
+    try:
+        out, _ = reader.communicate(timeout=120)
+        feeder.wait(timeout=60)
+        for p in procs:
+            p.wait(timeout=60)
+    finally:
+        for p in procs + [feeder, reader]:
+            if p.poll() is None:
+                p.kill()
+        subprocess.run([B("oat-clean-hip"), a_raw, a_f, a_pos], capture_output=True)
+    assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
+    return [json.loads(l) for l in out.splitlines() if l.strip()]
+
+
+@pytest.mark.gpu
+def test_framefilt_mask_and_bsub_read_pnm_files(host_bins, tmp_path):
+    """`framefilt mask -f FILE` (FrameMasker.cpp:45-75) and `framefilt bsub -f FILE` (BackgroundSubtractor.cpp:52-100)
+    from the binaries, with Netpbm files standing in for cv::imread: two bright squares, the mask / the
+    background image removes the left one, the detector must report the right one's centroid."""
+    import oracle_lib as O
+    rows, cols = 96, 128
+    f = np.zeros((rows, cols), np.uint8)
+    f[20:40, 10:30] = 200           # left square  (area 400)
+    f[50:70, 80:110] = 220          # right square (area 600)
+    frames = [f.copy() for _ in range(4)]
+    p = O.hsv_params(h_lo=100, h_hi=256, erode=0, dilate=0, min_area=4.0, max_area=1e5)
+    # mask: keep only the right half
+    m = np.zeros((rows, cols), np.uint8)
+    m[:, 64:] = 255
+    _write_pnm(tmp_path / "m.pgm", m)
+    got = _grey_chain(host_bins, tmp_path, frames, ["mask", "-f", str(tmp_path / "m.pgm")])
+    want, _ = O.detect_thresh(np.where(m > 0, f, 0).astype(np.uint8), p)
+    assert len(got) == 4 and want["valid"]
+    for g in got:
+        assert g["pos_ok"] and abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4
+    # bsub: background file holds the left square only -> saturating subtraction leaves the right one
+    bg = np.zeros((rows, cols), np.uint8)
+    bg[20:40, 10:30] = 200
+    _write_pnm(tmp_path / "bg.pgm", bg)
+    got = _grey_chain(host_bins, tmp_path, frames, ["bsub", "-f", str(tmp_path / "bg.pgm")])
+    want, _ = O.detect_thresh(np.clip(f.astype(int) - bg, 0, 255).astype(np.uint8), p)
+    assert len(got) == 4 and want["valid"]
+    for g in got:
+        assert g["pos_ok"] and abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4

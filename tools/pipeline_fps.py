@@ -2,7 +2,10 @@
 """Wall-clock throughput of the drop-in PROCESS pipeline over shared memory (the reference's own
 perf methodology, test/perf/*.sh: `time` a free-running frame server with the consumer chain attached).
 
-    python tools/pipeline_fps.py [--rows 480 --cols 640] [--frames 1000] [--fused]
+    python tools/pipeline_fps.py [--rows 480 --cols 640] [--frames 1000] [--fused] [--cameras N] [--ring D]
+
+--cameras N (with --fused): N free-running frame servers -> ONE batched, pipelined oat-track-hip -> N readers;
+the reported rate is the aggregate over all cameras.
 """
 import argparse
 import os
@@ -18,13 +21,61 @@ sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "build", "bin")
 
 
+def batched(a):
+    from oat_amd.synth import SyntheticStream
+    tag = "oat_p_" + uuid.uuid4().hex[:6]
+    B = lambda n: os.path.join(BIN, n)
+    n = a.cameras
+    srcs = [f"{tag}raw{s}" for s in range(n)]
+    snks = [f"{tag}pos{s}" for s in range(n)]
+    raws = []
+    for s in range(n):
+        st = SyntheticStream(a.rows, a.cols, s, n_discs=2)
+        raw = f"/dev/shm/oat_pipe_{uuid.uuid4().hex[:8]}.raw"
+        np.stack([st.frame(t, with_discs=t > 0) for t in range(8)]).tofile(raw)
+        raws.append(raw)
+    # readers write to FILES: n pipes drained one after the other would fill up and stall the whole pipeline
+    outs = [open(f"/dev/shm/{x}.out", "w+") for x in snks]
+    readers = [subprocess.Popen([B("oat-posi-cout"), x], stdout=o, text=True) for x, o in zip(snks, outs)]
+    tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
+                                "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
+                                "--ring", str(a.ring)])
+    time.sleep(4.0)
+    t0 = time.perf_counter()
+    feeders = [subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", raws[s], "--rows", str(a.rows), "--cols",
+                                 str(a.cols), "-n", str(a.frames)]) for s in range(n)]
+    tokens = ok = 0
+    for r in readers:
+        r.wait(timeout=300)
+    el = time.perf_counter() - t0
+    for o in outs:
+        o.seek(0)
+        out = o.read()
+        o.close()
+        os.unlink(o.name)
+        tokens += len([l for l in out.splitlines() if l.strip()])
+        ok += sum('"pos_ok":true' in l for l in out.splitlines())
+    for f in feeders:
+        f.wait(timeout=60)
+    tracker.wait(timeout=60)
+    for raw in raws:
+        os.unlink(raw)
+    subprocess.run([B("oat-clean-hip")] + srcs + snks, capture_output=True)
+    print(f"batched oat-track-hip, {n} cameras x {a.cols}x{a.rows}, ring {a.ring}: {tokens} tokens in {el:.2f} s = "
+          f"{tokens / el:.1f} fps aggregate, {tokens / el / n:.1f} per camera ({ok} valid positions)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--cameras", type=int, default=1)
+    ap.add_argument("--ring", type=int, default=2)
     a = ap.parse_args()
+    if a.cameras > 1:
+        return batched(a)
     from oat_amd.synth import SyntheticStream
     st = SyntheticStream(a.rows, a.cols, 0, n_discs=2)
     pool = np.stack([st.frame(t, with_discs=t > 0) for t in range(16)])
