@@ -130,6 +130,10 @@ private:
 
 }  // namespace detail
 
+// Everything below, down to the selection at the end of the file, is the NATIVE transport (POSIX shm + sem_t).
+// shmemdf_boost.hpp holds the same classes over Boost.Interprocess with stock Oat's bytes (namespace stock).
+namespace native {
+
 // ----------------------------------------------------------------------------- Node --
 class Node {
 public:
@@ -227,6 +231,8 @@ private:
     sem_t rb_[NUM_SLOTS];
 };
 
+}  // namespace native
+
 namespace detail {
 
 // what sits at the start of "<addr>_obj": which token type the segment carries
@@ -241,15 +247,17 @@ template <typename T> struct TypeName;
 template <> struct TypeName<Position2D> { static const char *get() { return "N3oat10Position2DE"; } };
 template <> struct TypeName<SharedFrameHeader> { static const char *get() { return "N3oat17SharedFrameHeaderE"; } };
 
-inline Node *open_node(Segment &seg, const std::string &node_address)
+inline native::Node *open_node(Segment &seg, const std::string &node_address)
 {
-    const bool created = seg.open_or_create(node_address, 1024 + sizeof(Node));
-    Node *n = (Node *)seg.base();
+    const bool created = seg.open_or_create(node_address, 1024 + sizeof(native::Node));
+    native::Node *n = (native::Node *)seg.base();
     if (created) n->construct(); else n->wait_constructed();
     return n;
 }
 
 }  // namespace detail
+
+namespace native {
 
 // --------------------------------------------------------------------------- SinkBase --
 template <typename T>
@@ -487,4 +495,19 @@ private:
     FrameParams parameters_;
 };
 
+}  // namespace native
+
 }  // namespace oat
+
+// ---- which transport the components use ----
+// OAT_SHMEM_BOOST (set by host/Makefile where <boost/interprocess/managed_shared_memory.hpp> exists): stock Oat's
+// Boost.Interprocess bytes, i.e. these binaries attach to unmodified oat-* processes; otherwise the native one.
+#if defined(OAT_SHMEM_BOOST)
+#include "shmemdf_boost.hpp"
+#if !defined(OAT_HAVE_BOOST_INTERPROCESS)
+#error "OAT_SHMEM_BOOST was requested but <boost/interprocess/managed_shared_memory.hpp> is not available"
+#endif
+namespace oat { using namespace stock; }
+#else
+namespace oat { using namespace native; }
+#endif
