@@ -69,3 +69,69 @@ def gather_positions(local_positions, n_streams_total, device, dst=0, group=None
     if rank != dst:
         return None
     return torch.cat(bufs)[:n_streams_total].cpu()
+
+
+class FrameScatterPipe:
+    """Double-buffered stream->rank scatter for the topology where all frames originate on ONE rank (a camera
+    host): the frames of step t+1 travel while step t computes.
+
+    One 1080p stream is 6.2 MB; at BASELINE config 4 (64 streams, 8 per GPU) the root sends 49.8 MB to each of
+    its 7 peers per step -- about 0.33 ms on one xGMI link (point-to-point: the 7 blocks use the 7 links in
+    parallel, which is why this is send/recv per peer and not a ring collective) -- the same order as the
+    0.25-0.5 ms compute step, so the transfer has to hide under the previous step:
+
+        pipe.post(0, frames0)                 # root: frames0[n_streams_total, ...]; other ranks: None
+        for t in range(T):
+            if t + 1 < T: pipe.post(t + 1, frames(t + 1))      # starts moving while ...
+            local = pipe.take(t)                               # ... step t is taken and computed
+            compute(local)
+
+    post(t) uses buffer slot t % depth, so take(t)'s tensor stays valid until post(t + depth).  Backend "nccl"
+    (= RCCL) on the GPU box; the tests drive the same code over gloo.  Unmeasured on multi-GPU hardware so far
+    (the builder has one GPU at a time): the driver's SCALE run uses per-rank ingest, not this path."""
+
+    def __init__(self, n_streams_total, frame_shape, device, src=0, group=None, depth=2):
+        self.total, self.shape, self.device, self.src, self.group = n_streams_total, tuple(frame_shape), device, src, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.per = -(-n_streams_total // self.world)
+        self.mine = stream_partition(n_streams_total, self.world, self.rank)
+        self.depth = depth
+        self.buf = [torch.empty((self.per,) + self.shape, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.work = [None] * depth          # outstanding requests of the slot
+        self.keep = [None] * depth          # root: the frame tensor being sent out of
+        self.step_of = [None] * depth
+
+    def post(self, t, frames_root=None):
+        k = t % self.depth
+        if self.work[k] is not None:
+            raise RuntimeError(f"slot of step {self.step_of[k]} was never taken")
+        ops = []
+        if self.rank == self.src:
+            fr = frames_root if frames_root.device == self.buf[k].device else frames_root.to(self.device, non_blocking=True)
+            assert fr.shape[0] == self.total and tuple(fr.shape[1:]) == self.shape
+            self.keep[k] = fr
+            for peer in range(self.world):
+                blk = stream_partition(self.total, self.world, peer)
+                if not len(blk):
+                    continue
+                chunk = fr[blk.start:blk.stop]
+                if peer == self.rank:
+                    self.buf[k][:len(blk)].copy_(chunk, non_blocking=True)
+                else:
+                    ops.append(dist.P2POp(dist.isend, chunk.contiguous(), peer, self.group))
+        elif len(self.mine):
+            ops.append(dist.P2POp(dist.irecv, self.buf[k][:len(self.mine)], self.src, self.group))
+        self.work[k] = dist.batch_isend_irecv(ops) if ops else []
+        self.step_of[k] = t
+
+    def take(self, t):
+        k = t % self.depth
+        if self.step_of[k] != t or self.work[k] is None:
+            raise RuntimeError(f"step {t} was not posted (slot holds {self.step_of[k]})")
+        for w in self.work[k]:
+            w.wait()
+        if self.buf[k].is_cuda:
+            torch.cuda.current_stream(self.buf[k].device).synchronize()   # the hot path runs on its own HIP streams
+        self.work[k] = None
+        self.keep[k] = None
+        return self.buf[k][:len(self.mine)]

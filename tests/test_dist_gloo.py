@@ -70,3 +70,54 @@ def test_scatter_and_gather_world2(total):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _pipe_worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shape, T = (4, 5, 3), 7
+        mine = od.stream_partition(total, world, rank)
+
+        def frames(t):          # every byte encodes (step, stream)
+            f = torch.empty((total,) + shape, dtype=torch.uint8)
+            for s in range(total):
+                f[s] = (17 * t + 3 * s) % 251
+            return f
+        pipe = od.FrameScatterPipe(total, shape, torch.device("cpu"), src=0, depth=2)
+        ok = True
+        pipe.post(0, frames(0) if rank == 0 else None)
+        for t in range(T):
+            if t + 1 < T:
+                pipe.post(t + 1, frames(t + 1) if rank == 0 else None)     # in flight while step t is consumed
+            local = pipe.take(t)
+            ok = ok and local.shape[0] == len(mine)
+            for i, s in enumerate(mine):
+                ok = ok and bool((local[i] == (17 * t + 3 * s) % 251).all())
+        # protocol errors are reported, not silently reordered
+        try:
+            pipe.take(T + 5)
+            ok = False
+        except RuntimeError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [3, 8])
+def test_double_buffered_scatter_keeps_step_order_world2(total):
+    """The transfer of step t+1 is posted before step t is taken; every rank must still see
+    exactly its own streams of exactly step t."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}
