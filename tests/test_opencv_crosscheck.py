@@ -1,0 +1,80 @@
+"""The oracle against a REAL OpenCV -- the check that would pin parity (SURVEY.md 8c last row).
+
+Skipped where cv2 is missing, which is everywhere this repo has run so far: neither the build container nor the
+GPU box has OpenCV in any form (profiles/r02_opencv_probe.txt).  It is written so that whoever has `cv2` only
+has to run `pytest tests/test_opencv_crosscheck.py -rs`:
+
+  * the reference pins OpenCV 3.1.0 (README.md:1613); cv2 >= 3.2 pads instead of zeroing the 1-px frame in
+    findContours, so the contour images keep an empty border ring and both behaviours give the same result;
+  * the three points the judge could not verify from memory are targeted first: the MOG2 mode count
+    (`nmodes = nNewModes;`, oracle/mog2.c "Mode count") -- the test says WHICH reading matches --, the list order
+    of findContours (tie-break) and the even-k dilation anchor.
+Call sites being checked: BackgroundSubtractorMOG.cpp:82-83,124; ColorConvert.cpp:104; HSVDetector.cpp:146-156;
+DetectorFunc.cpp:41-63."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+cv2 = pytest.importorskip("cv2", reason="no OpenCV in this image (profiles/r02_opencv_probe.txt): parity stays unpinned")
+
+
+def test_bgr2hsv_matches_cvtcolor():
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (256, 4096, 3), dtype=np.uint8)
+    assert (O.bgr2hsv(bgr) == cv2.cvtColor(bgr, cv2.COLOR_BGR2HSV)).all()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 7, 10])
+def test_rect_morphology_matches_cv(k):
+    rng = np.random.default_rng(k)
+    img = np.where(rng.random((61, 83)) < 0.5, 255, 0).astype(np.uint8)
+    el = cv2.getStructuringElement(cv2.MORPH_RECT, (k, k))
+    assert (O.erode(img, k) == cv2.erode(img, el)).all()
+    assert (O.dilate(img, k) == cv2.dilate(img, el)).all(), "even-k dilation anchor / reflection differs"
+
+
+def _ringed(img):
+    img = img.copy()
+    img[:2, :] = img[-2:, :] = 0
+    img[:, :2] = img[:, -2:] = 0
+    return img
+
+
+def test_external_contours_moments_and_list_order_match_cv():
+    rng = np.random.default_rng(3)
+    for i in range(200):
+        img = _ringed(np.where(rng.random((50, 70)) < rng.choice([0.2, 0.5]), 255, 0).astype(np.uint8))
+        res = cv2.findContours(img.copy(), cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+        contours = res[-2]
+        mine = O.find_contours(img)
+        assert len(mine) == len(contours), i
+        for a, b in zip(mine, contours):                      # SAME ORDER: the tie-break of siftContours depends on it
+            m = cv2.moments(b)
+            assert a["start"] == tuple(int(v) for v in b[0][0]), i
+            assert abs(a["m00"] - m["m00"]) < 1e-9 and abs(a["m10"] - m["m10"]) < 1e-6 and abs(a["m01"] - m["m01"]) < 1e-6, i
+
+
+def test_mog2_masks_match_cv_and_report_the_mode_count_reading():
+    rng = np.random.default_rng(11)
+    rows, cols = 48, 64
+    base = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
+    alt = rng.integers(0, 256, (rows, cols, 3)).astype(np.int16)
+    verdict = {}
+    for rate in (0.0, 0.01, 0.3):
+        for restore in (1, 0):
+            ref = cv2.createBackgroundSubtractorMOG2()
+            orc = O.Mog2(rows, cols, 3, params=dict(restore_nmodes=restore))
+            r2 = np.random.default_rng(5)
+            same = True
+            for t in range(150):
+                f = np.where(r2.random((rows, cols, 1)) < 0.25, alt, base) + r2.integers(-12, 13, (rows, cols, 3))
+                f = np.clip(f, 0, 255).astype(np.uint8)
+                same = same and bool((ref.apply(f, learningRate=rate) == orc.apply(f, rate)).all())
+            verdict[(rate, restore)] = same
+    print("MOG2 mask identity with cv2 by (rate, restore_nmodes):", verdict)
+    assert verdict[(0.0, 1)] and verdict[(0.0, 0)], "frozen-model masks differ from OpenCV"
+    good = [r for r in (1, 0) if all(verdict[(rate, r)] for rate in (0.0, 0.01, 0.3))]
+    assert good, f"neither reading of the mode count reproduces OpenCV {cv2.__version__}: {verdict}"
+    assert 1 in good, ("OpenCV %s prunes the mode count (restore_nmodes = 0): flip the default of "
+                       "oatgpu_config.mog_restore_nmodes / oat_mog2_params.restore_nmodes" % cv2.__version__)
