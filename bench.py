@@ -464,10 +464,22 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
         con = sqlite3.connect(db)
         rows = con.execute("select kernel_name, value, duration from counters_collection where counter_name = ? "
                            "order by start", (counter,)).fetchall()
-        vals = [(v, d) for k, v, d in rows if "k_mog_fused" in k][-K:]
-        if not vals:
+        # the per-pixel stage is one kernel or two (K1a + K1b, kernels_mog.hip): per instantiation the average over
+        # its last K dispatches, summed over the instantiations = per step
+        per = {}
+        for k, v, d in rows:
+            if "k_mog_fused" in k:
+                per.setdefault(k, []).append((v, d))
+        if not per:
             return None
-        return sum(v for v, _ in vals) / len(vals), sum(d for _, d in vals) / len(vals) / 1e3, len(vals)
+        val = dur = 0.0
+        n = 0
+        for lst in per.values():
+            lst = lst[-K:]
+            val += sum(v for v, _ in lst) / len(lst)
+            dur += sum(d for _, d in lst) / len(lst) / 1e3
+            n = max(n, len(lst))
+        return val, dur, n
     except Exception as e:      # never let a profiler problem break the benchmark line
         log(f"pmc pass {workload} {counter} failed: {e}")
         return None

@@ -352,6 +352,14 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     Geom &g = c->g;
     g.H = cfg->rows; g.W = cfg->cols; g.Wp = (cfg->cols + 63) / 64 * 64; g.words = g.Wp / 64;
     g.P = g.H * g.Wp; g.Palloc = (g.P + 1023) / 1024 * 1024; g.n_streams = cfg->n_streams;
+    g.words_magic = (unsigned)((0x100000000ull + (unsigned)g.words - 1) / (unsigned)g.words);
+    // (i * magic) >> 32 == i / words needs i * (magic * words - 2^32) < 2^32; the error term is < words
+    if ((unsigned long long)(g.Palloc / 64) * (unsigned long long)g.words >= 0x100000000ull ||
+        (unsigned long long)mog_stream_floats(g.Palloc) * 4ull >= 0x100000000ull) {     // 32-bit plane offsets in K1
+        fail(nullptr, OATGPU_E_INVALID, "frame too large");
+        delete c;
+        return nullptr;
+    }
     const size_t n = cfg->n_streams, npx = (size_t)g.H * g.W, PA = g.Palloc, NW = PA / 64;
     c->nframes.assign(n, 0);
     c->diff_have.assign(n, 0);

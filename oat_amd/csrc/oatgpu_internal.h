@@ -23,6 +23,7 @@ struct Geom {
     int P;               // H * Wp
     int Palloc;          // P rounded up to 1024
     int n_streams;
+    unsigned words_magic; // ceil(2^32 / words): row of mask word i = (i * words_magic) >> 32, exact for every word of a frame
 };
 
 // MOG2 model in HBM (per stream): 25 fp32 planes + one u8 plane (mode counters), 101 B/px.

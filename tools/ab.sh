@@ -12,7 +12,7 @@ import json, sys
 try:
     j = json.load(open(sys.argv[1]))
     r = j["roofline"]
-    print(f"{sys.argv[2]:12s} {sys.argv[3]:48s} fps {j['value']:9.1f}  step {j['ms_per_step']*1e3:7.1f} us  K1 {r['avg_launch_ms']*1e3:7.1f} us  blob {j['stage_ms']['blob']*1e3:6.1f} us  parity {j['parity']}")
+    print(f"{sys.argv[2]:12s} {sys.argv[3]:48s} fps {j['value']:9.1f}  step {j['ms_per_step']*1e3:7.1f} us  K1 {r['benched_workload']['avg_launch_ms']*1e3:7.1f} us  blob {j['stage_ms']['blob']*1e3:6.1f} us  parity {j['parity']}")
 except Exception as e:
     print(sys.argv[2], sys.argv[3], "FAILED", e)
 PY
