@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-2 evidence, collected on the GPU box from the repo root:   bash profiles/collect_r02.sh [tag]
+#   1. the default bench line (4k1 + in-run dense leg + PMC child passes + extra workloads + cpu_baseline)
+#   2. rocprofv3 --kernel-trace --stats of the dense 4K run (the roofline leg) and of the benched sparse 4K run:
+#      the k_mog_fused averages there must agree with roofline.avg_launch_ms / benched_workload.avg_launch_ms
+#   3. SQ-side counters of k_mog_fused (what the kernel is bound by)
+# Output under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.log
+cd /tmp && export TMPDIR=/tmp
+for leg in dense sparse; do
+  args="--workload 4k1 --steps 300 --warmup 100 --quick --no-parity --no-spin-up"
+  [ $leg = dense ] && args="$args --dense-model" || args="$args --no-dense-leg"
+  rm -rf /tmp/kt_$leg
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_$leg -o r -- python $R/bench.py $args > $O/${TAG}_bench_4k1_${leg}_traced.json 2> /tmp/kt_$leg.err
+  db=$(find /tmp/kt_$leg -name "*.db" | head -1)
+  {
+    echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py $args"
+    echo
+    echo "Per-kernel statistics of this library's kernels, first 101 dispatches of every kernel skipped (frame 1 + warm-up):"
+    echo
+    python $R/profiles/summarize_rocpd.py $db 101
+    echo
+    echo "bench line of the traced run (HIP-event time of the same kernel on its own stream):"
+    python - "$O/${TAG}_bench_4k1_${leg}_traced.json" <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1]))
+b = j["roofline"]["benched_workload"]
+print(f"  value {j['value']:.1f} fps, ms_per_step {j['ms_per_step']:.4f}, k_mog_fused avg_launch_ms (events) {b['avg_launch_ms']:.4f}")
+PY
+  } > $O/${TAG}_kernel_stats_4k1_${leg}.md
+done
+cd $R
+bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_sparse --workload 4k1 --steps 40 --warmup 100 > /dev/null 2>&1
+bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_dense --workload 4k1 --dense-model --steps 40 --warmup 20 > /dev/null 2>&1
+ls -la $O | grep ${TAG}_
