@@ -72,9 +72,10 @@ def main():
                    sigma_accel=float(rng.choice([5.0, 40.0])), sigma_noise=float(rng.choice([0.0, 1.0])))
         mode = str(rng.choice(["sync", "dev", "host"]))
         frames = make_frames(rng, rows, cols, n, nframes, channels)
+        restore = int(rng.integers(0, 2))          # both readings of MOG2Invoker's mode count (oracle/mog2.c)
 
         hp = oat_amd.HotPath(rows, cols, n_streams=n, ring_depth=ring, channels=channels, adaptation_coeff=lr,
-                             erode=e, dilate=d, area=area, **win)
+                             erode=e, dilate=d, area=area, mog_restore_nmodes=restore, **win)
         if use_kal:
             hp.set_kalman(True, **kal)
         pkw = dict(erode=e, dilate=d, min_area=area[0], max_area=area[1])
@@ -84,7 +85,7 @@ def main():
         else:
             pkw.update(h_lo=win["h_thresh"][0], h_hi=256)
         p = O.hsv_params(**pkw)
-        orc = [O.Mog2(rows, cols, channels) for _ in range(n)]
+        orc = [O.Mog2(rows, cols, channels, params=dict(restore_nmodes=restore)) for _ in range(n)]
         okal = [O.Kalman(**kal) for _ in range(n)]
 
         got, masks = [], []
