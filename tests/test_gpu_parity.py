@@ -942,3 +942,94 @@ print(json.dumps(out))
             assert got[t][1:] == [want["a00"], want["a10"], want["a01"], want["first_pixel"]], (t, got[t], want)
             nvalid += 1
     assert nvalid >= 3
+
+
+# ------------------------------------------------ round-2 entry points of the C ABI --
+
+def test_traffic_audit_counts_what_the_kernel_moves(A):
+    """oatgpu_traffic_audit: the audited instantiation of the per-pixel kernel must (i) leave every result as it
+    is, (ii) count close to the full 104 B/px of reads on an input with five live modes where the matching one is
+    rarely the first, and far less on a static scene -- where a matched single-mode pixel costs 24 B read
+    (3 BGR + 1 counter + 20 mode 0) and 20 B written."""
+    rows, cols = 64, 128
+    rng = np.random.default_rng(5)
+    table = np.array([[20, 30, 40], [90, 200, 60], [200, 60, 120], [240, 240, 230], [40, 130, 220]], np.int16)
+    phase = rng.integers(0, 5, (rows, cols))
+    hp = A.HotPath(rows, cols, n_streams=1, adaptation_coeff=0.05, erode=0, dilate=0, area=(1.0, 1e9))
+    ref = A.HotPath(rows, cols, n_streams=1, adaptation_coeff=0.05, erode=0, dilate=0, area=(1.0, 1e9))
+    frames = [np.clip(table[(phase + t) % 5] + rng.integers(-4, 5, (rows, cols, 3)), 0, 255).astype(np.uint8) for t in range(40)]
+    for f in frames[:30]:
+        hp.track([f]); ref.track([f])
+    hp.traffic_audit(True)
+    for f in frames[30:]:
+        assert hp.track([f]) == ref.track([f])                      # same results with the audit on
+    t = hp.traffic_read()
+    hp.traffic_audit(False)
+    assert t["launches"] == 10 and t["pixels"] == 10 * rows * cols
+    # nearly every lane loads every plane, the counter and the pixel (104 B); never more than that
+    assert 80 * t["pixels"] <= t["lane_bytes_read"] <= 104 * t["pixels"]
+    assert t["lane_bytes_read"] <= t["sector32_bytes_read"] <= t["sector64_bytes_read"] <= 128 * t["pixels"]
+    assert 20 * t["pixels"] <= t["lane_bytes_written"] <= 101 * t["pixels"]
+    for a, b in zip(hp.mog_state(), ref.mog_state()):
+        assert (np.asarray(a) == np.asarray(b)).all()
+    # a static scene: one mode everywhere
+    st = A.HotPath(rows, cols, n_streams=1, adaptation_coeff=0.05, erode=0, dilate=0, area=(1.0, 1e9))
+    still = np.full((rows, cols, 3), 90, np.uint8)
+    for _ in range(5):
+        st.track([still])
+    st.traffic_audit(True)
+    st.track([still])
+    u = st.traffic_read()
+    # + the threshold mask: one 8-byte word per 64 pixels
+    assert u["lane_bytes_read"] == 24 * rows * cols and u["lane_bytes_written"] == 20 * rows * cols + rows * cols // 8
+
+
+def test_mask_filter_and_bsub_background_entry_points(A):
+    """oatgpu_mask_filter (FrameMasker.cpp:71-75) and oatgpu_bsub_set_background (BackgroundSubtractor.cpp:63-71)."""
+    import ctypes as C
+    from oat_amd import ffi
+    rows, cols = 37, 70
+    rng = np.random.default_rng(9)
+    f = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    m = (rng.random((rows, cols)) < 0.5).astype(np.uint8) * 255
+    g = A.BackgroundSubtractorMOG(rows, cols)
+    out = np.empty_like(f)
+    g._chk(g.lib.oatgpu_mask_filter(g.ctx, 0, ffi.u8(f), ffi.u8(out)))
+    assert (out == f).all()                                           # no mask set: untouched
+    g.set_roi_mask(m)
+    g._chk(g.lib.oatgpu_mask_filter(g.ctx, 0, ffi.u8(f), ffi.u8(out)))
+    assert (out == np.where(m[..., None] != 0, f, 0)).all()
+    bg = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    b = A.BackgroundSubtractor(rows, cols, adaptation_coeff=0.0)
+    b._chk(b.lib.oatgpu_bsub_set_background(b.ctx, 0, ffi.u8(bg)))
+    assert (b.filter(f) == np.clip(f.astype(int) - bg, 0, 255)).all()  # frame - background, saturating
+    adapt = A.BackgroundSubtractor(rows, cols, adaptation_coeff=0.1)
+    adapt._chk(adapt.lib.oatgpu_bsub_set_background(adapt.ctx, 0, ffi.u8(bg)))
+    with pytest.raises(A.OatGpuError):                               # the reference's accumulateWeighted asserts here
+        adapt.filter(f)
+
+
+def test_track_ready_and_input_consumed(A):
+    """The two calls the batched C++ component pipelines with: after input_consumed the host frames may be
+    overwritten; track_ready turns 1 once the oldest result can be collected without blocking."""
+    import time
+    rows, cols, n = 120, 160, 2
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), ring_depth=3,
+                   **disc_hsv_window())
+    ref = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+    streams = [SyntheticStream(rows, cols, 40 + s, n_discs=1, radius=10) for s in range(n)]
+    assert hp.lib.oatgpu_track_ready(hp.ctx) == 0                    # nothing outstanding
+    bufs = [np.empty((rows, cols, 3), np.uint8) for _ in range(n)]    # ONE set of host buffers, reused every step
+    for t in range(8):
+        frames = [st.frame(t, with_discs=t > 0) for st in streams]
+        for b, f in zip(bufs, frames):
+            b[...] = f
+        hp.enqueue(bufs)
+        hp._chk(hp.lib.oatgpu_track_input_consumed(hp.ctx))
+        for b in bufs:
+            b[...] = 0                                                # scribble: the device must have its copy by now
+        deadline = time.time() + 10
+        while hp.lib.oatgpu_track_ready(hp.ctx) != 1:
+            assert time.time() < deadline
+        assert hp.collect() == ref.track(frames), t
