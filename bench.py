@@ -60,6 +60,7 @@ ALPHA = 0.01
 RESTORE = 1                     # MOG2Invoker's `nmodes = nNewModes;` (oracle/mog2.c "Mode count"); 0 = the other reading
 AREA = (20.0, 1e5)
 RING = 8
+AGE = 600                       # frames a model has seen before anything is warmed up or timed (see timed_run)
 MIN_TIMED_MS = 50.0             # below this a timed region says little: flagged in the line
 
 
@@ -114,21 +115,25 @@ def parity_gate(wl, device, frames_seq):
     return "ok"
 
 
-def measured_run_gate(wl, frames_of_step, got_positions, tag=""):
-    """SURVEY.md 8d 'parity gates run with every benchmark': the positions the TIMED run itself produced for
-    one camera stream, step by step, against the oracle chain run over the very same frame sequence (model
-    init, warm-up, timed steps).  frames_of_step: host frames of that stream in run order;
-    got_positions: (step index in that order, Position2D) pairs to compare."""
+def measured_run_gate(wl, state, frames_of_step, got_positions, tag=""):
+    """SURVEY.md 8d 'parity gates run with every benchmark': the positions the TIMED run itself produced for one
+    camera stream against the oracle chain.  The model is AGED on the device first (hundreds to thousands of
+    frames: a young model is a transient, not the workload), so the oracle does not replay the history: it takes
+    over the device's model as exported right after the ageing (`state` = HotPath.mog_state(): counters, weights,
+    variances, means, frame count) and runs the very frames that followed -- warm-up, then the timed steps.
+    frames_of_step: host frames of that stream from the hand-over on; got_positions: (index into them, Position2D)."""
     import oracle_lib as O
     orc = oracle_mog(wl)
+    nm, w, v, m, nframes = state
+    orc.set_state(nm, w, v, m, nframes)
     p = oracle_params(wl)
     want = [O.chain_step(orc, f, ALPHA, p, nthreads=host_threads())[0] for f in frames_of_step]
     for t, g in got_positions:
-        w = want[t]
-        if g.position_valid != w["valid"]:
+        w_ = want[t]
+        if g.position_valid != w_["valid"]:
             return f"{tag}valid mismatch at run frame {t}"
-        if w["valid"] and ((g.a00, g.a10, g.a01) != (w["a00"], w["a10"], w["a01"]) or
-                           abs(g.x - w["x"]) > 1e-4 or abs(g.y - w["y"]) > 1e-4):
+        if w_["valid"] and ((g.a00, g.a10, g.a01) != (w_["a00"], w_["a10"], w_["a01"]) or
+                            abs(g.x - w_["x"]) > 1e-4 or abs(g.y - w_["y"]) > 1e-4):
             return f"{tag}centroid mismatch at run frame {t}"
     return "ok"
 
@@ -279,6 +284,21 @@ class Leg:
         self.hp.track_dev(self.pool[0].data_ptr())
         self.step = 1
 
+    def age(self, min_frames, min_seconds=0.0):
+        """Run the model to working age (untimed): at least min_frames frames and min_seconds of device time."""
+        t0 = time.perf_counter()
+        n = 0
+        while n < min_frames or time.perf_counter() - t0 < min_seconds:
+            k = max(1, min(200, min_frames - n)) if n < min_frames else 100
+            self.run(k)
+            n += k
+        self.hp.synchronize()
+        return n
+
+    def export_models(self):
+        """Every stream's model as the oracle takes it over (HotPath.mog_state())."""
+        return [self.hp.mog_state(s) for s in range(self.ns)]
+
     def prepare(self, n):
         """Argument arrays of an n-step run, built outside the timed region."""
         import ctypes as C
@@ -333,9 +353,10 @@ class Leg:
 
 
 def spin_up(name, dev_index, rank, seconds):
-    """Warm the DEVICE (clocks, allocator, first-launch costs) with a scratch context of the same workload
-    before the real one runs its W warm-up steps: the driver's default run times only a few milliseconds,
-    which on a cold device measured 19 k instead of 28 k fps in round 1.  Not part of W or K."""
+    """Warm the DEVICE (clocks, allocator, first-launch costs) with a scratch context of the same workload right
+    before the real one runs its W warm-up steps (the model export for the parity gate leaves the device idle
+    for a moment, and the driver's default run times only a few milliseconds: on a cold device round 1 measured
+    19 k instead of 28 k fps).  Not part of W or K; never touches the measured models."""
     leg = Leg(name, dev_index, rank + 1000, pool=4)      # (never the dense generator: any warm device will do)
     leg.init()
     t0 = time.perf_counter()
@@ -348,12 +369,19 @@ def spin_up(name, dev_index, rank, seconds):
     return n
 
 
-def timed_run(leg, K, W, barrier, prof_every):
-    """W warm-up steps, then EXACTLY K timed steps between barriers.  Returns elapsed seconds, the K x ns
-    positions, and the HIP-event profile of the timed steps."""
+def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0, spin_args=None):
+    """Model initialisation, ageing (untimed), [export of the aged models for the parity gate, device spin-up on a
+    scratch context while the real one rests], W warm-up steps, then EXACTLY K timed steps between barriers.
+    Returns elapsed seconds, the K x ns positions, the HIP-event profile of the timed steps, the exported models,
+    the step index of the hand-over and the number of ageing frames."""
     from oat_amd.components import Position2D
     hp = leg.hp
     leg.init()
+    aged = leg.age(age_frames) if age_frames > 0 else 0
+    models = leg.export_models() if export else None
+    handover = leg.step                 # first frame the oracle will see after taking the models over
+    if spin > 0 and spin_args:
+        spin_up(*spin_args, spin)       # the export left the device idle: warm it again, on a scratch context
     if W:
         leg.run(W)
     hp.profile(prof_every)       # HIP events around K1 on every prof_every-th step of the timed region
@@ -368,7 +396,7 @@ def timed_run(leg, K, W, barrier, prof_every):
     hp.profile(0)
     ns = leg.ns
     positions = [[Position2D.from_c(out[t * ns + s]) for s in range(ns)] for t in range(K)]
-    return elapsed, positions, prof
+    return elapsed, positions, prof, models, handover, aged
 
 
 def k1_ms(prof):
@@ -378,25 +406,26 @@ def k1_ms(prof):
     return max(raw - prof["event_pair_ms"], 1e-6), raw
 
 
-def gates(leg, W, K, positions, check_steps):
+def gates(leg, W, K, positions, check_steps, models, handover):
     """Both parity gates for this leg's run, every stream of the rank."""
     wl = leg.wl
     first = [leg.pool[leg.pool_index(i)][0].cpu().numpy() for i in range(4)]
     res = parity_gate(wl, leg.dev.index, first)
     log(f"[{leg.name}] parity gate (fresh context, 4 frames, masks + centroids):", res)
-    if res != "ok" or check_steps <= 0:
+    if res != "ok" or check_steps <= 0 or models is None:
         return res, None
     G = min(check_steps, K)
-    order = [leg.pool_index(i) for i in range(1 + W + G)]
+    order = [leg.pool_index(handover + i) for i in range(W + G)]
     for s in range(leg.ns):
         host = {i: leg.pool[i][s].cpu().numpy() for i in set(order)}
-        res = measured_run_gate(wl, [host[i] for i in order], [(1 + W + i, positions[i][s]) for i in range(G)],
+        res = measured_run_gate(wl, models[s], [host[i] for i in order], [(W + i, positions[i][s]) for i in range(G)],
                                 tag=f"stream {s}: ")
         if res != "ok":
             break
-    log(f"[{leg.name}] measured-run gate ({G} timed steps x {leg.ns} stream(s) vs oracle):", res)
+    log(f"[{leg.name}] measured-run gate ({G} timed steps x {leg.ns} stream(s) vs oracle from the aged model):", res)
     detail = (f"fresh-context masks+centroids on 4 frames; first {G} timed steps of every one of the {leg.ns} "
-              f"stream(s) vs the oracle replayed over the run's own frame sequence: {res}")
+              f"stream(s) vs the oracle continuing from the device's exported model (age {handover} frames) over the "
+              f"run's own frames: {res}")
     return res, detail
 
 
@@ -429,6 +458,7 @@ def pmc_child(args):
     torch.cuda.set_device(0)
     leg = Leg(args.workload, 0, 0, dense=args.dense_model, pool=10 if args.dense_model else args.pool)
     leg.init()
+    leg.age(args.age)
     leg.run(args.warmup)
     leg.run(args.steps)
     leg.hp.synchronize()
@@ -445,7 +475,7 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
     tmp = tempfile.mkdtemp(prefix="oat_pmc_", dir="/tmp")
     cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--steps", str(K), "--warmup", str(W),
-           "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA)]
+           "--age", str(AGE if not dense else 60), "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA)]
     if dense:
         cmd.append("--dense-model")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -559,9 +589,14 @@ def main():
     ap.add_argument("--mog-restore-nmodes", type=int, default=1, choices=[0, 1],
                     help="1 (default): MOG2Invoker's `nmodes = nNewModes;` -- pruned modes keep their slot; 0: pruning "
                          "shrinks the mode count (round 1's reading); oracle/mog2.c 'Mode count'")
+    ap.add_argument("--age", type=int, default=600,
+                    help="frames every model has seen (untimed) before the W warm-up and the K timed steps: a model a few "
+                         "frames old is a transient (SURVEY 8d measures behind a warm-up; with this reading of the mode "
+                         "count the model keeps changing for a few hundred frames); 0 = as young as W makes it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    global ALPHA, RESTORE
+    global ALPHA, RESTORE, AGE
+    AGE = args.age
     RESTORE = args.mog_restore_nmodes
     if args.learning_rate is not None:
         ALPHA = args.learning_rate
@@ -594,10 +629,6 @@ def main():
     K, W = args.steps, args.warmup
     t_start = time.perf_counter()
 
-    spin_steps = 0
-    if not args.no_spin_up:
-        spin_steps = spin_up(args.workload, local_rank, rank, 0.35)
-
     leg = Leg(args.workload, local_rank, rank, dense=args.dense_model, pool=10 if args.dense_model else args.pool,
               input_mode=args.input)
 
@@ -607,12 +638,16 @@ def main():
         if world > 1:
             dist.barrier()
 
-    elapsed, positions, prof = timed_run(leg, K, W, barrier, prof_every=8 if K >= 64 else 1)
+    want_gate = rank == 0 and not args.no_parity and not args.dense_model and args.input == "device"
+    elapsed, positions, prof, models, handover, aged = timed_run(
+        leg, K, W, barrier, prof_every=8 if K >= 64 else 1, age_frames=AGE, export=want_gate,
+        spin=0.0 if args.no_spin_up else 0.35, spin_args=(args.workload, local_rank, rank))
     n_found_local = sum(p.position_valid for r in positions for p in r)
 
     parity, parity_detail = "skipped", None
-    if rank == 0 and not args.no_parity and not args.dense_model and args.input == "device":
-        parity, parity_detail = gates(leg, W, K, positions, args.check_steps)
+    if want_gate:
+        parity, parity_detail = gates(leg, W, K, positions, args.check_steps, models, handover)
+    models = None
 
     # the kernel's own traffic count and the model's mode histogram, continuing this run's model
     aud = hist = None
@@ -669,7 +704,8 @@ def main():
                 dense = dict(avg_launch_ms=mog_ms, px_per_launch=px_per_launch, steps=K, audit=aud)
             else:
                 dl = Leg("4k1", local_rank, rank, dense=True, pool=10)
-                d_el, _, d_prof = timed_run(dl, 120, 20, lambda: (dl.hp.synchronize(), torch.cuda.synchronize()), 1)
+                d_el, _, d_prof, _, _, _ = timed_run(dl, 120, 20, lambda: (dl.hp.synchronize(), torch.cuda.synchronize()), 1,
+                                                     age_frames=60, export=False)
                 d_aud = audit(dl, 4)
                 dense = dict(avg_launch_ms=k1_ms(d_prof)[0], px_per_launch=3840 * 2160, steps=120,
                              ms_per_step=d_el / 120 * 1e3, audit=d_aud)
@@ -738,15 +774,15 @@ def main():
         "config": {"workload": f"{ns} x {cols}x{rows} uchar3 stream(s) per GPU, MOG2(5 mixtures, lr {ALPHA}) + HSV + "
                                f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
                    "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
-                   "learning_rate": ALPHA, "mog_restore_nmodes": RESTORE,
+                   "learning_rate": ALPHA, "mog_restore_nmodes": RESTORE, "model_age_frames": handover,
                    "parallelism": f"streams sharded, {world} rank(s)"},
         "fps_per_gpu": fps / world,
         "timed_region_ms": elapsed * 1e3,
         "timed_region_note": (None if elapsed * 1e3 >= MIN_TIMED_MS else
                               f"timed region shorter than {MIN_TIMED_MS:.0f} ms: exactly --steps {K} were timed as the "
-                              f"contract asks, behind a {spin_steps}-step device spin-up on a scratch context and {W} "
-                              f"warm-up steps"),
-        "spin_up_steps": spin_steps,
+                              f"contract asks, on models aged {aged} frames (untimed), behind a device spin-up on a "
+                              f"scratch context and {W} warm-up steps"),
+        "model_age_frames": handover,
         "roofline": roofline,
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),
@@ -767,10 +803,13 @@ def main():
                 continue
             try:
                 el_ = Leg(name, local_rank, rank, pool=24 if name == "1080p16" else 48)
-                e_el, e_pos, e_prof = timed_run(el_, kk, ww, lambda: (el_.hp.synchronize(), torch.cuda.synchronize()), 8)
+                e_el, e_pos, e_prof, e_models, e_ho, _ = timed_run(
+                    el_, kk, ww, lambda: (el_.hp.synchronize(), torch.cuda.synchronize()), 8, age_frames=AGE,
+                    export=not args.no_parity, spin=0.0 if args.no_spin_up else 0.2, spin_args=(name, local_rank, rank))
                 e_par = "skipped"
                 if not args.no_parity:
-                    e_par, _ = gates(el_, ww, kk, e_pos, min(args.check_steps, 16))
+                    e_par, _ = gates(el_, ww, kk, e_pos, min(args.check_steps, 16), e_models, e_ho)
+                e_models = None
                 e_aud = audit(el_, 4)
                 w_ = WORKLOADS[name]
                 ppl = w_["rows"] * w_["cols"] * w_["streams"]

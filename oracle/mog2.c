@@ -100,6 +100,21 @@ void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float
     if (mean) memcpy(mean, m->mean, n * m->ch * sizeof(float));
 }
 
+/* Test plumbing (no OpenCV counterpart): continue from a model that was exported elsewhere -- bench.py ages a
+ * model on the GPU, hands it over and lets the oracle check the frames that follow. */
+void oat_mog2_set_state(oat_mog2 *m, const uint8_t *modes_used, const float *weight, const float *variance,
+                        const float *mean, int nframes)
+{
+    size_t npx = (size_t)m->rows * m->cols, n = npx * m->p.nmixtures;
+    memcpy(m->modes_used, modes_used, npx);
+    for (size_t i = 0; i < n; i++) {
+        m->gmm[i].weight = weight[i];
+        m->gmm[i].variance = variance[i];
+    }
+    memcpy(m->mean, mean, n * m->ch * sizeof(float));
+    m->nframes = nframes;
+}
+
 /* detectShadowGMM (bgfg_gaussmix2.cpp) */
 static int detect_shadow_gmm(const float *data, int nchannels, int nmodes,
                              const gmm_t *gmm, const float *mean,

@@ -72,6 +72,8 @@ void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning
 void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
 
 /* State inspection (tests / parity): per pixel, `nmixtures` entries. */
+void oat_mog2_set_state(oat_mog2 *m, const uint8_t *modes_used, const float *weight, const float *variance,
+                        const float *mean, int nframes);   /* test plumbing: continue from an exported model */
 int oat_mog2_nframes(const oat_mog2 *m);
 int oat_mog2_channels(const oat_mog2 *m);
 const uint8_t *oat_mog2_modes_used(const oat_mog2 *m);         /* rows*cols */

@@ -70,6 +70,7 @@ def _load():
     lib.oat_mog2_modes_used.argtypes = [C.c_void_p]
     fp = C.POINTER(C.c_float)
     lib.oat_mog2_get_state.argtypes = [C.c_void_p, fp, fp, fp]
+    lib.oat_mog2_set_state.argtypes = [C.c_void_p, u8p, fp, fp, fp, C.c_int]
     lib.oat_bgr2hsv.argtypes = [u8p, u8p, C.c_size_t]
     ip = C.POINTER(C.c_int)
     lib.oat_inrange3.argtypes = [u8p, C.c_size_t, ip, ip, u8p]
@@ -142,6 +143,13 @@ class Mog2:
         mask = np.empty((self.rows, self.cols), np.uint8)
         lib.oat_mog2_filter_mt(self.h, _p(frame), _p(mask), float(lr), int(nthreads))
         return frame, mask
+
+    def set_state(self, nm, w, v, m, nframes):
+        """Continue from a model exported elsewhere (HotPath.mog_state() order: modes_used, weight, variance, mean)."""
+        nm = _c(nm)
+        w, v, m = (np.ascontiguousarray(a, np.float32) for a in (w, v, m))
+        f = C.POINTER(C.c_float)
+        lib.oat_mog2_set_state(self.h, _p(nm), w.ctypes.data_as(f), v.ctypes.data_as(f), m.ctypes.data_as(f), int(nframes))
 
     def state(self):
         n = self.rows * self.cols
