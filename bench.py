@@ -68,6 +68,28 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pin_to_gpu_node(dev_index):
+    """Keep this process on the CPUs of the NUMA node the GPU hangs off.  The small workloads are bound by the
+    host's launch calls (a 1080p step is ~35 us of HIP API work), and after the many-threaded oracle gates the
+    scheduler may leave the driving thread on the far socket: the same leg then measured 15.8 k instead of 27.9 k
+    fps.  Best effort; returns the node or None."""
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/numa_node"))
+        amd = [c for c in cards if open(os.path.join(os.path.dirname(c), "vendor")).read().strip() == "0x1002"]
+        node = int(open(amd[dev_index % len(amd)]).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or cpus)
+        return node
+    except Exception:
+        return None
+
+
 def make_hotpath(wl, device, ring_depth=RING, dense=False, n_streams=None):
     import oat_amd
     from oat_amd.synth import disc_hsv_window
@@ -628,6 +650,7 @@ def main():
     rows, cols, ns = wl["rows"], wl["cols"], wl["streams"]
     K, W = args.steps, args.warmup
     t_start = time.perf_counter()
+    numa_node = pin_to_gpu_node(local_rank)
 
     leg = Leg(args.workload, local_rank, rank, dense=args.dense_model, pool=10 if args.dense_model else args.pool,
               input_mode=args.input)
@@ -644,10 +667,8 @@ def main():
         spin=0.0 if args.no_spin_up else 0.35, spin_args=(args.workload, local_rank, rank))
     n_found_local = sum(p.position_valid for r in positions for p in r)
 
-    parity, parity_detail = "skipped", None
-    if want_gate:
-        parity, parity_detail = gates(leg, W, K, positions, args.check_steps, models, handover)
-    models = None
+    # (the parity gates -- minutes of many-threaded CPU work -- run after ALL device timing of this process: the small
+    # workloads are bound by the host's launch calls and measured up to 40 % lower behind them)
 
     # the kernel's own traffic count and the model's mode histogram, continuing this run's model
     aud = hist = None
@@ -676,6 +697,23 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- the other BASELINE configs: device timing now, their gates later ----
+    extra_runs = []
+    if solo and not args.no_extra and args.input == "device" and not args.dense_model:
+        for name, kk, ww in (("1080p16", 200, 40), ("1080p1", 1500, 100)):
+            if name == args.workload:
+                continue
+            try:
+                el_ = Leg(name, local_rank, rank, pool=24 if name == "1080p16" else 48)
+                e_el, e_pos, e_prof, e_models, e_ho, _ = timed_run(
+                    el_, kk, ww, lambda: (el_.hp.synchronize(), torch.cuda.synchronize()), 8, age_frames=AGE,
+                    export=not args.no_parity, spin=0.0 if args.no_spin_up else 0.2, spin_args=(name, local_rank, rank))
+                e_aud = audit(el_, 4)
+                extra_runs.append(dict(name=name, leg=el_, K=kk, W=ww, el=e_el, pos=e_pos, prof=e_prof, models=e_models,
+                                       handover=e_ho, aud=e_aud))
+            except Exception as e:
+                log(f"extra workload {name} failed:", e)
+
     total_streams = ns * world
     fps = total_streams * K / elapsed
     px_per_launch = rows * cols * ns
@@ -692,10 +730,6 @@ def main():
                        requested_sector32_bytes_per_px=aud["sector32_read_B_per_px"] + aud["sector32_write_B_per_px"],
                        requested_sector64_bytes_per_px=aud["sector64_read_B_per_px"] + aud["sector64_write_B_per_px"],
                        audit=aud, mode_histogram=hist)
-    leg.close()
-    del leg
-    torch.cuda.empty_cache()
-
     # ---- the leg where the algorithmic bytes really move: 4K, all five modes live on every pixel ----
     dense = None
     if solo and not args.no_dense_leg and args.input == "device":
@@ -714,6 +748,31 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:
             log("dense leg failed:", e)
+
+    # ---- parity gates of everything timed above (CPU), then the legs can go ----
+    parity, parity_detail = "skipped", None
+    if want_gate:
+        parity, parity_detail = gates(leg, W, K, positions, args.check_steps, models, handover)
+    models = None
+    leg.close()
+    del leg
+    extra = {}
+    for er in extra_runs:
+        e_par = "skipped"
+        if not args.no_parity:
+            e_par, _ = gates(er["leg"], er["W"], er["K"], er["pos"], min(args.check_steps, 16), er["models"], er["handover"])
+        w_ = WORKLOADS[er["name"]]
+        ppl = w_["rows"] * w_["cols"] * w_["streams"]
+        e_k1 = k1_ms(er["prof"])[0]
+        extra[er["name"]] = dict(value=w_["streams"] * er["K"] / er["el"], unit="frames/s", steps=er["K"], warmup=er["W"],
+                                 model_age_frames=er["handover"], ms_per_step=er["el"] / er["K"] * 1e3, k_mog_fused_ms=e_k1,
+                                 useful_bytes_per_px=er["aud"]["useful_read_B_per_px"] + er["aud"]["useful_write_B_per_px"],
+                                 requested_sector32_bytes_per_px=er["aud"]["sector32_read_B_per_px"] + er["aud"]["sector32_write_B_per_px"],
+                                 algorithmic_rate_GBps=BYTES_PER_PIXEL * ppl / (e_k1 * 1e-3) / 1e9, parity=e_par)
+        er["leg"].close()
+        er["models"] = er["leg"] = None
+    extra_runs = []
+    torch.cuda.empty_cache()
 
     pmc = None
     if solo and dense and not args.no_pmc and args.input == "device":
@@ -783,6 +842,7 @@ def main():
                               f"contract asks, on models aged {aged} frames (untimed), behind a device spin-up on a "
                               f"scratch context and {W} warm-up steps"),
         "model_age_frames": handover,
+        "host_numa_node": numa_node,
         "roofline": roofline,
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),
@@ -795,35 +855,7 @@ def main():
         "dense_model": bool(args.dense_model),
     }
 
-    # ---- the other BASELINE configs, same measurement, shorter runs ----
     if solo and not args.no_extra and args.input == "device" and not args.dense_model:
-        extra = {}
-        for name, kk, ww in (("1080p16", 200, 40), ("1080p1", 1500, 100)):
-            if name == args.workload:
-                continue
-            try:
-                el_ = Leg(name, local_rank, rank, pool=24 if name == "1080p16" else 48)
-                e_el, e_pos, e_prof, e_models, e_ho, _ = timed_run(
-                    el_, kk, ww, lambda: (el_.hp.synchronize(), torch.cuda.synchronize()), 8, age_frames=AGE,
-                    export=not args.no_parity, spin=0.0 if args.no_spin_up else 0.2, spin_args=(name, local_rank, rank))
-                e_par = "skipped"
-                if not args.no_parity:
-                    e_par, _ = gates(el_, ww, kk, e_pos, min(args.check_steps, 16), e_models, e_ho)
-                e_models = None
-                e_aud = audit(el_, 4)
-                w_ = WORKLOADS[name]
-                ppl = w_["rows"] * w_["cols"] * w_["streams"]
-                extra[name] = dict(value=w_["streams"] * kk / e_el, unit="frames/s", steps=kk, warmup=ww,
-                                   ms_per_step=e_el / kk * 1e3, k_mog_fused_ms=k1_ms(e_prof)[0],
-                                   useful_bytes_per_px=e_aud["useful_read_B_per_px"] + e_aud["useful_write_B_per_px"],
-                                   requested_sector32_bytes_per_px=e_aud["sector32_read_B_per_px"] + e_aud["sector32_write_B_per_px"],
-                                   algorithmic_rate_GBps=BYTES_PER_PIXEL * ppl / (k1_ms(e_prof)[0] * 1e-3) / 1e9,
-                                   parity=e_par)
-                el_.close()
-                del el_
-                torch.cuda.empty_cache()
-            except Exception as e:
-                log(f"extra workload {name} failed:", e)
         line["extra_workloads"] = extra
 
     if not args.no_cpu_baseline and solo:          # rank 0 at N = 1 only (the other ranks would idle meanwhile)
