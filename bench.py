@@ -547,10 +547,10 @@ def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense):
     kernel's own access pattern: the dense pass is that -- the kernel's audit gives its read and written bytes
     exactly -- and `bytes_per_launch_calibrated` applies the two factors found there."""
     out = dict(method="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE: separate child passes of this very run, "
-                      "KiB units, averaged over the last 24 k_mog_fused dispatches; bytes_per_launch = 2 x FETCH_SIZE + "
+                      "KiB units, averaged over the last 48 k_mog_fused dispatches (one pool cycle); bytes_per_launch = 2 x FETCH_SIZE + "
                       "WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); *_calibrated = factors fitted "
                       "on the dense pass against the kernel's audited bytes")
-    K = 24
+    K = 48                      # one whole cycle of the 48-frame pool: the traffic varies with where the discs are
     df = pmc_pass("4k1", True, "FETCH_SIZE", 12, K)
     dw = pmc_pass("4k1", True, "WRITE_SIZE", 12, K)
     if not df or not dw:
