@@ -235,29 +235,6 @@ __device__ __forceinline__ bool in_range3(int a, int b, int c, const RangeParams
            c >= rp.lo[2] && c <= rp.hi[2];
 }
 
-// Model plane access.  OATGPU_NT=1 marks the streamed planes nontemporal (A/B option: the bare access
-// pattern likes it, tools/k1_lab.hip; the kernel does not -- the Infinity Cache keeps much of a sparse
-// model across frames and the streaming policy gives that up: 4K 100 -> 116-120 us, r02 ab1).
-#ifndef OATGPU_NT
-#define OATGPU_NT 0
-#endif
-__device__ __forceinline__ float ld_plane(const float *src)
-{
-#if OATGPU_NT
-    return __builtin_nontemporal_load(src);
-#else
-    return *src;
-#endif
-}
-__device__ __forceinline__ void st_plane(float *dst, float v)
-{
-#if OATGPU_NT
-    __builtin_nontemporal_store(v, dst);
-#else
-    *dst = v;
-#endif
-}
-
 // Traffic audit (oatgpu_traffic_audit): the SAME kernel with every load / store predicate also counted --
 // bytes the lanes ask for ("useful": what the arithmetic can depend on) and the 32-byte sectors / 64-byte
 // half lines those requests touch (what the memory system has to move at least).  A separate template
@@ -276,6 +253,19 @@ struct Audit {
         const unsigned n32 = 32u * (unsigned)__popcll(b), n64 = 64u * (unsigned)__popcll(h);
         if (wr) { lane_wr += m ? 4u : 0u; s32_wr += n32; s64_wr += n64; }
         else { lane_rd += m ? 4u : 0u; s32_rd += n32; s64_rd += n64; }
+    }
+    // NB-byte records of consecutive lanes (NB = 8 or 16): 32 / NB lanes per sector, 64 / NB per half line
+    template <int NB>
+    __device__ __forceinline__ void rec(bool m, bool wr)
+    {
+        if (!AUDIT) return;
+        const u64 bal = __ballot(m);
+        u64 b = bal, h = bal;
+        if (NB == 16) { b |= b >> 1; b &= 0x5555555555555555ull; h |= h >> 2; h |= h >> 1; h &= 0x1111111111111111ull; }
+        else { b |= b >> 2; b |= b >> 1; b &= 0x1111111111111111ull; h |= h >> 4; h |= h >> 2; h |= h >> 1; h &= 0x0101010101010101ull; }
+        const unsigned n32 = 32u * (unsigned)__popcll(b), n64 = 64u * (unsigned)__popcll(h);
+        if (wr) { lane_wr += m ? (unsigned)NB : 0u; s32_wr += n32; s64_wr += n64; }
+        else { lane_rd += m ? (unsigned)NB : 0u; s32_rd += n32; s64_rd += n64; }
     }
     // one byte per lane (the counter plane): the wave's 64 bytes are two sectors / one half line
     __device__ __forceinline__ void byte(bool m, bool wr)
@@ -338,35 +328,53 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     const size_t npx = (size_t)g.H * g.W;
     const uint8_t *frame = a.frames + (size_t)s * npx * CH;
     float *sbase = a.state + (size_t)s * mog_stream_floats(g.Palloc);       // uniform
-    const size_t PS = mog_plane_stride(g.Palloc);
-    // Plane access through ONE buffer resource over the stream's model: address = base + lane offset (one VGPR,
-    // shared by all planes) + plane offset (a scalar) -- no vector instruction per access.  (As 64-bit flat
-    // addresses hipcc spent two VALU per access on them: ~100 of the 370 VALU instructions per wave.)
+    // Model access through ONE buffer resource over the stream's model: address = base + lane offset (a VGPR shared
+    // by all modes: p*4 for the weights, p*16 for the {variance, mean} records) + mode offset (a scalar) -- no
+    // vector instruction per access.  (As 64-bit flat addresses hipcc spent two VALU per access: ~100 of the 370
+    // VALU instructions per wave.)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(mog_stream_floats(g.Palloc) * 4), 0x00020000);
-    const unsigned PSB = (unsigned)(PS * 4);
-#if OATGPU_TILE
-#define SOFF(slot) ((unsigned)(kTilePx + (slot) * PSB))
-#else
-#define SOFF(slot) ((unsigned)(slot) * PSB)
-#endif
-#define LDP(slot) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, boff, SOFF(slot), 0))
-#define STP(slot, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, boff, SOFF(slot), 0)
-#if OATGPU_TILE
-    const unsigned poff = (p / kTilePx) * kTileFloats + (p % kTilePx);   // float index of pixel p inside a tile record (+ SOFF)
-    uint8_t *nmbase = (uint8_t *)sbase;
-    const unsigned coff = (p / kTilePx) * kTileFloats * 4u + (p % kTilePx);
-#else
-    const unsigned poff = p;
+    const unsigned PA4 = (unsigned)g.Palloc * 4u;
+    const unsigned voff_w = p * 4u, voff_r = p * 4u * (1 + CH);     // a stream's model stays below 4 GiB (oatgpu_create)
+#define SW(k) ((unsigned)(k) * ((2 + CH) * PA4 + 8u * (unsigned)kPlanePad))
+#define SR(k) (SW(k) + PA4 + 4u * (unsigned)kPlanePad)
+#define LDW(k) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
+#define STW(k, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 0)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // (records are LOADED through `uniform pointer + 32-bit lane offset` global loads: ROCm 7.2's hipcc compiles
+    // __builtin_amdgcn_raw_buffer_load_b128 / _b64 into ONE dword load whose value it replicates -- the stores and the
+    // 4-byte loads through the resource are fine)
+    auto ld_rec = [&](int k, float &v, float *m) {                  // {variance, mean[CH]} of mode k
+        const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
+        if (CH == 3) {
+            const float4 q = *(const float4 *)rp;
+            v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+        } else {
+            const float2 q = *(const float2 *)rp;
+            v = q.x; m[0] = q.y;
+        }
+    };
+    auto st_rec = [&](int k, float v, const float *m) {
+        if (CH == 3) {
+            u32x4 q;
+            q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
+            q.z = __builtin_bit_cast(unsigned, m[1]); q.w = __builtin_bit_cast(unsigned, m[2]);
+            __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
+        } else {
+            u32x2 q;
+            q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
+            __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, voff_r, SR(k), 0);
+        }
+    };
     uint8_t *nmbase = a.nmodes + (size_t)s * g.Palloc;
     const unsigned coff = p;
-#endif
-    const unsigned boff = poff * 4u;              // a stream's model stays below 4 GiB (oatgpu_create checks)
     // a word's 64 pixels lie in one row (Wp is a multiple of 64): row = widx / words, by multiply-high
     const unsigned y = g.words == 1 ? widx : (unsigned)(((u64)widx * g.words_magic) >> 32);
     const unsigned x = (widx - y * (unsigned)g.words) * 64u + lpos;
     const bool valid = active && (x < (unsigned)g.W);
     const unsigned fi = (y * (unsigned)g.W + x) * CH;                        // frames stay below 4 GiB per stream
 #define AU_DW(m, wr) au.dword((m), (wr))
+#define AU_REC(m, wr) au.template rec<4 * (1 + CH)>((m), (wr))
 #define AU_B(m, wr) au.byte((m), (wr))
 
     // ---- phase 1: counter byte, mode 0, the pixel -- for every lane, nothing depends on anything ----
@@ -378,13 +386,11 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     // (no `active` guard: the planes are allocated for Palloc pixels, a multiple of the block's 256)
     if (!a.fresh) {
         cnt = nmbase[coff];
-        pm.w[0] = LDP(slot_w(0));
-        pm.v[0] = LDP(slot_v(0));
-#pragma unroll
-        for (int c = 0; c < CH; ++c) pm.m[0][c] = LDP(slot_m(0, c));
+        pm.w[0] = LDW(0);
+        ld_rec(0, pm.v[0], pm.m[0]);
         AU_B(active, false);
-#pragma unroll
-        for (int c = 0; c < 2 + CH; ++c) AU_DW(active, false);
+        AU_DW(active, false);
+        AU_REC(active, false);
     }
     // no branch around the pixel loads either (lanes beyond the image read pixel 0 and ignore it)
     {
@@ -421,15 +427,10 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
         for (int k = 1; k < kMaxMix; ++k) {
             const bool have = valid && k < nold;
             const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
-            if (lw) pm.w[k] = LDP(slot_w(k));
-            if (have && full) {
-                pm.v[k] = LDP(slot_v(k));
-#pragma unroll
-                for (int c = 0; c < CH; ++c) pm.m[k][c] = LDP(slot_m(k, c));
-            }
+            if (lw) pm.w[k] = LDW(k);
+            if (have && full) ld_rec(k, pm.v[k], pm.m[k]);
             AU_DW(lw, false);
-#pragma unroll
-            for (int c = 0; c < 1 + CH; ++c) AU_DW(have && full, false);
+            AU_REC(have && full, false);
         }
     }
 
@@ -481,15 +482,10 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     for (int k = 0; k < kMaxMix; ++k) {
         const bool was_live = k == 0 || full || ((cnt >> (kLiveShift + k)) & 1);
         const bool sw = work && wchg && k < nlive && was_live, svm = (dvm >> k) & 1u;
-        if (sw) STP(slot_w(k), pm.w[k]);
-        if (svm) {
-            STP(slot_v(k), pm.v[k]);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) STP(slot_m(k, c), pm.m[k][c]);
-        }
+        if (sw) STW(k, pm.w[k]);
+        if (svm) st_rec(k, pm.v[k], pm.m[k]);
         AU_DW(sw, true);
-#pragma unroll
-        for (int c = 0; c < 1 + CH; ++c) AU_DW(svm, true);
+        AU_REC(svm, true);
         if (k >= 1 && k < nnew && pm.w[k] != 0.f) newcnt |= 1 << (kLiveShift + k);
     }
     const bool sc = work && (newcnt != cnt || a.fresh);
@@ -500,10 +496,12 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * nwords + widx] = word;
     au.run(a.thr_bits && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
-#undef LDP
-#undef STP
-#undef SOFF
+#undef LDW
+#undef STW
+#undef SW
+#undef SR
 #undef AU_DW
+#undef AU_REC
 #undef AU_B
 }
 
@@ -728,22 +726,19 @@ void launch_unpack_bits(const Geom &g, const u64 *bits, uint8_t *out, hipStream_
     hipLaunchKernelGGL(k_unpack_bits, dim3(blocks), dim3(256), 0, st, g, bits, out);
 }
 
-// ---- model checkpoint: device planes <-> OpenCV's logical AoS order ----
-__device__ __forceinline__ float *state_elem(const Geom &g, float *sbase, int plane, int p)
+// ---- model checkpoint: device layout <-> OpenCV's logical AoS order ----
+__device__ __forceinline__ float *w_elem(const Geom &g, float *sbase, int ch, int k, int p)
 {
-    const int base = p - (p % kWavePx);
-    return sbase + mog_plane_off(g.Palloc, plane, base) + (p - base);
+    return sbase + mog_w_off(g.Palloc, ch, k) + p;
+}
+__device__ __forceinline__ float *rec_elem(const Geom &g, float *sbase, int ch, int k, int p, int field)   // 0: variance, 1 + c: mean[c]
+{
+    return sbase + mog_vm_off(g.Palloc, ch, k) + (size_t)p * (1 + ch) + field;
 }
 __device__ __forceinline__ uint8_t *count_elem(const Geom &g, float *sbase, uint8_t *nmodes, int p)
 {
-#if OATGPU_TILE
-    const int base = p - (p % kWavePx);
-    (void)nmodes;
-    return (uint8_t *)sbase + mog_count_off(g.Palloc, base) + (p - base);
-#else
-    (void)sbase;
+    (void)g; (void)sbase;
     return nmodes + p;
-#endif
 }
 
 __global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint8_t *nmodes, int nmix, int ch,
@@ -756,10 +751,10 @@ __global__ __launch_bounds__(256) void k_state_export(Geom g, float *state, uint
         const int p = y * g.Wp + x;
         modes_used[i] = *count_elem(g, state, nmodes, p) & kCountMask;     // the live hints stay inside
         for (int k = 0; k < nmix; ++k) {
-            weight[i * nmix + k] = *state_elem(g, state, slot_w(k), p);
-            variance[i * nmix + k] = *state_elem(g, state, slot_v(k), p);
+            weight[i * nmix + k] = *w_elem(g, state, ch, k, p);
+            variance[i * nmix + k] = *rec_elem(g, state, ch, k, p, 0);
             for (int c = 0; c < ch; ++c)
-                mean[(i * nmix + k) * ch + c] = *state_elem(g, state, slot_m(k, c), p);
+                mean[(i * nmix + k) * ch + c] = *rec_elem(g, state, ch, k, p, 1 + c);
         }
     }
 }
@@ -777,10 +772,10 @@ __global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint
             if (weight[i * nmix + k] != 0.f) cnt |= 1 << (kLiveShift + k);
         *count_elem(g, state, nmodes, p) = (uint8_t)cnt;
         for (int k = 0; k < nmix; ++k) {
-            *state_elem(g, state, slot_w(k), p) = weight[i * nmix + k];
-            *state_elem(g, state, slot_v(k), p) = variance[i * nmix + k];
+            *w_elem(g, state, ch, k, p) = weight[i * nmix + k];
+            *rec_elem(g, state, ch, k, p, 0) = variance[i * nmix + k];
             for (int c = 0; c < ch; ++c)
-                *state_elem(g, state, slot_m(k, c), p) = mean[(i * nmix + k) * ch + c];
+                *rec_elem(g, state, ch, k, p, 1 + c) = mean[(i * nmix + k) * ch + c];
         }
     }
 }

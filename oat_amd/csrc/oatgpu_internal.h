@@ -47,44 +47,21 @@ constexpr int kWavePx = 64;               // pixels one wavefront owns
 constexpr int kCountMask = 7;
 constexpr int kLiveShift = 2;             // live bit of slot k is bit kLiveShift + k (k >= 1)
 
-// Where the planes live.  Default (OATGPU_TILE = 0): plane-major arrays of Palloc entries, counters in
-// an array of their own.  OATGPU_TILE = 256 (A/B option): everything the 256 pixels of one K1 workgroup
-// need is ONE contiguous 25.25 KiB record -- 256 counter bytes, then the 25 planes of those pixels in
-// SLOT order.  The bare access pattern likes tiles + the streaming cache policy (6.45 TB/s against
-// 5.77 TB/s for plane-major, tools/k1_lab.hip, profiles/r02_k1_lab.txt); the real kernel does not
-// (profiles/r02_k1_layout_ab.txt: dense 4K K1 383 vs 400 us, but the everyday sparse model 109 vs 100 us,
-// and with nontemporal accesses 120 us): a sparse model's hot part -- mode 0 -- is 174 MB of dense
-// arrays at 4K, which the 256 MiB Infinity Cache keeps from frame to frame.
-// Slot order: the five planes of a mode are adjacent -- weight, variance, mean[3].
-#ifndef OATGPU_TILE
-#define OATGPU_TILE 0
+// Where the model lives.  Per mode k: a WEIGHT plane (fp32[Palloc]) and a plane of {variance, mean[channels]}
+// RECORDS (fp32[Palloc][1 + channels]: 16 bytes per pixel for BGR, 8 for GREY), mode after mode; the counter bytes
+// in an array of their own.  Weights stand alone because they are what changes every frame on every live mode;
+// variance and mean travel together (a mode's fit test, update and swap always touch all of them): one 16-byte
+// access per lane -- 1 KiB per wave instruction for mode 0, which every pixel reads and rewrites every frame --
+// and a lane that needs a later mode touches ONE half-sector of it instead of a sector in each of four planes.
+// (Round 1 and the first half of round 2 kept 25 scalar planes; profiles/r02_k1_layout_ab.txt also has the
+// measurements of 256-pixel tile records and of the nontemporal cache policy, both rejected.)
+#ifndef OATGPU_PAD
+#define OATGPU_PAD 0
 #endif
-constexpr int kTilePx = OATGPU_TILE;
-static_assert(kTilePx == 0 || (kTilePx % kWavePx == 0 && 1024 % kTilePx == 0), "tile must hold whole wave tiles and divide Palloc");
-__host__ __device__ constexpr int slot_w(int k) { return 5 * k; }
-__host__ __device__ constexpr int slot_v(int k) { return 5 * k + 1; }
-__host__ __device__ constexpr int slot_m(int k, int c) { return 5 * k + 2 + c; }
-#if OATGPU_TILE
-constexpr int kTileFloats = kTilePx / 4 + kMogPlanes * kTilePx;
-__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)(Palloc / kTilePx) * kTileFloats; }
-// float offset (within a stream) of slot `slot` for the wave tile that starts at pixel `base`
-__host__ __device__ inline size_t mog_plane_off(int Palloc, int slot, int base)
-{
-    (void)Palloc;
-    return (size_t)(base / kTilePx) * kTileFloats + kTilePx / 4 + (size_t)slot * kTilePx + (base % kTilePx);
-}
-__host__ __device__ inline size_t mog_plane_stride(int Palloc) { (void)Palloc; return kTilePx; }
-// byte offset (within a stream's float array) of the mode counters of the wave tile at `base`
-__host__ __device__ inline size_t mog_count_off(int Palloc, int base)
-{
-    (void)Palloc;
-    return (size_t)(base / kTilePx) * kTileFloats * 4 + (base % kTilePx);
-}
-#else
-__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)kMogPlanes * Palloc; }
-__host__ __device__ inline size_t mog_plane_off(int Palloc, int slot, int base) { return (size_t)slot * Palloc + base; }
-__host__ __device__ inline size_t mog_plane_stride(int Palloc) { return Palloc; }
-#endif
+constexpr size_t kPlanePad = OATGPU_PAD;     // floats between consecutive planes (A/B knob: DRAM channel alignment of the ten streams)
+__host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)kMogPlanes * Palloc + 10 * kPlanePad; }
+__host__ __device__ inline size_t mog_w_off(int Palloc, int ch, int k) { return (size_t)k * ((2 + ch) * (size_t)Palloc + 2 * kPlanePad); }
+__host__ __device__ inline size_t mog_vm_off(int Palloc, int ch, int k) { return mog_w_off(Palloc, ch, k) + Palloc + kPlanePad; }
 
 struct MogParams {
     float Tb, TB, Tg, varInit, varMin, varMax, tau;

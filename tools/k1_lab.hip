@@ -225,6 +225,32 @@ __global__ __launch_bounds__(256) void copy4e(const float *src, float *dst, size
 #include <functional>
 #include <string>
 
+// The record layout K1 uses since round 2: per mode a weight plane (4 B/px) and a {variance, mean[3]} record plane
+// (16 B/px), 1 px per lane, in place; PHASES = 2: mode 0 first, the other four behind a data-dependent test.
+template <int PHASES>
+__global__ __launch_bounds__(256) void planes_rec(float *st, uint8_t *nm, size_t P)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float w[5];
+    float4 r[5];
+    const int n = nm[p];
+    w[0] = st[p];
+    r[0] = *(const float4 *)(st + P + 4 * p);
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        float *wb = st + (size_t)k * 5 * P;
+        if (PHASES == 2) { w[k] = 0.f; r[k] = make_float4(0, 0, 0, 0); if (n > 1 && r[0].x >= 0.f) { w[k] = wb[p]; r[k] = *(const float4 *)(wb + P + 4 * p); } }
+        else { w[k] = wb[p]; r[k] = *(const float4 *)(wb + P + 4 * p); }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float *wb = st + (size_t)k * 5 * P;
+        wb[p] = w[k] + 1.0f;
+        *(float4 *)(wb + P + 4 * p) = make_float4(r[k].x + 1.f, r[k].y + 1.f, r[k].z + 1.f, r[k].w + 1.f);
+    }
+    nm[p] = (uint8_t)n;
+}
+
 struct Variant { std::string name; std::function<void()> launch; double bytes; std::vector<double> ms; };
 
 int main(int argc, char **argv)
@@ -257,6 +283,8 @@ int main(int argc, char **argv)
     C4(25, true, "copy4 full grid 25/thread nt")
     add("planes dword 1 phase (K1 today)", [&] { hipLaunchKernelGGL((planes_dword<1, 1>), dim3(nblk), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
     add("planes dword 2 phases (K1 today)", [&] { hipLaunchKernelGGL((planes_dword<2, 1>), dim3(nblk), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
+    add("planes rec layout 1 phase", [&] { hipLaunchKernelGGL((planes_rec<1>), dim3(nblk), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
+    add("planes rec layout 2 phases", [&] { hipLaunchKernelGGL((planes_rec<2>), dim3(nblk), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
     add("planes vec2 (regs)", [&] { hipLaunchKernelGGL((planes_vec<2, 1>), dim3(nblk / 2), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
     add("planes vec4 (regs)", [&] { hipLaunchKernelGGL((planes_vec<4, 1>), dim3(nblk / 4), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
     add("planes lds16 dma", [&] { hipLaunchKernelGGL((planes_lds16<1, 1>), dim3(nblk), dim3(256), 0, 0, st, nm, PS); }, bytes_planes);
