@@ -217,6 +217,9 @@ def cpu_baseline(name, frames_seq):
     return out
 
 
+LAB_CALM = False
+
+
 def make_pool_dense(rows, cols, ns, nframes, rank, dev):
     """The case where all 205 algorithmic B/px really move: every pixel cycles through FIVE well separated
     colours in a fixed order (own phase per pixel).  All five mixture modes stay live with near-equal weights, the
@@ -247,6 +250,8 @@ def make_pool_device(rows, cols, ns, nframes, rank, dev):
     base = 110 + 30 * (xx / max(cols - 1, 1)) + 20 * (yy / max(rows - 1, 1))
     base = torch.stack([base, base + 6, base - 5], -1).to(torch.int16)            # (rows, cols, 3)
     flick = ((torch.arange(rows * cols, device=dev) % 64) == 17).view(rows, cols)
+    if LAB_CALM:                                    # lab only (--lab-calm): no flickering pixel, the path every lane shares
+        flick = torch.zeros_like(flick)
     rmin = max(4, min(rows, cols) // 40)
     cpu_rng = np.random.default_rng(0x0A7 + rank)
     discs = []
@@ -616,9 +621,11 @@ def main():
                          "frames old is a transient (SURVEY 8d measures behind a warm-up; with this reading of the mode "
                          "count the model keeps changing for a few hundred frames); 0 = as young as W makes it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
-    global ALPHA, RESTORE, AGE
+    global ALPHA, RESTORE, AGE, LAB_CALM
     AGE = args.age
+    LAB_CALM = args.lab_calm
     RESTORE = args.mog_restore_nmodes
     if args.learning_rate is not None:
         ALPHA = args.learning_rate
@@ -829,7 +836,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not LAB_CALM else "synthetic, LAB: no flickering pixels (not the SURVEY 8d input)",
         "config": {"workload": f"{ns} x {cols}x{rows} uchar3 stream(s) per GPU, MOG2(5 mixtures, lr {ALPHA}) + HSV + "
                                f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
                    "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
