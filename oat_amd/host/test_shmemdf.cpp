@@ -32,7 +32,7 @@ template <typename F> static bool ready(F &f, std::chrono::milliseconds d = 5ms)
 static void node_tests()
 {
     // Node_test.cpp:28-78
-    Node *n = (Node *)aligned_alloc(64, sizeof(Node) + 64);
+    Node *n = (Node *)aligned_alloc(64, (sizeof(Node) + 127) / 64 * 64);
     n->construct();
     size_t idx = 0;
     for (size_t i = 0; i < Node::NUM_SLOTS; ++i) { CHECK(n->acquireSlot(idx) == 0); CHECK(idx == i); }
