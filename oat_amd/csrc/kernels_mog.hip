@@ -337,8 +337,16 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     const unsigned voff_w = p * 4u, voff_r = p * 4u * (1 + CH);     // a stream's model stays below 4 GiB (oatgpu_create)
 #define SW(k) ((unsigned)(k) * ((2 + CH) * PA4 + 8u * (unsigned)kPlanePad))
 #define SR(k) (SW(k) + PA4 + 4u * (unsigned)kPlanePad)
-#define LDW(k) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
-#define STW(k, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 0)
+// Modes >= OATGPU_NTK are accessed with the streaming (nontemporal) cache policy: slots 1..4 are touched by a few
+// per cent of the pixels of an everyday model (nothing worth keeping in the caches), and on a dense model everything
+// streams.  Measured (r02, gpurun ab21): dense 4K 306 -> 295 us, sparse unchanged; mode 0 too (NTK = 0): sparse
+// unchanged, dense 293 / 332 us in two runs -- mode 0 keeps the default policy.
+#ifndef OATGPU_NTK
+#define OATGPU_NTK 1
+#endif
+#define LDW(k) __builtin_bit_cast(float, (k) >= OATGPU_NTK ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
+#define STW(k, v) do { if ((k) >= OATGPU_NTK) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 2); \
+                       else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 0); } while (0)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     // Records are LOADED through `uniform pointer + 32-bit lane offset` global loads.  Measured alternatives (r02,
@@ -351,7 +359,8 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     auto ld_rec = [&](int k, float &v, float *m) {                  // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
         if (CH == 3) {
-            const float4 q = *(const float4 *)rp;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 q = k >= OATGPU_NTK ? __builtin_nontemporal_load((const f32x4 *)rp) : *(const f32x4 *)rp;
             v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
         } else {
             const float2 q = *(const float2 *)rp;
@@ -363,7 +372,8 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
             u32x4 q;
             q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
             q.z = __builtin_bit_cast(unsigned, m[1]); q.w = __builtin_bit_cast(unsigned, m[2]);
-            __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
+            if (k >= OATGPU_NTK) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
         } else {
             u32x2 q;
             q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
