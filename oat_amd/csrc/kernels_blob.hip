@@ -176,10 +176,20 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     if (ERODE) {
         const int r0 = blockIdx.x * 4 - dk / 2;
         const int n = (4 + dk - 1) * g.words;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int rr = i / g.words, w = i - rr * g.words;
-            const int yy = r0 + rr;
-            er[i] = (yy < 0 || yy >= g.H) ? 0ull : erode_word(g, src_img, yy, w, ero_k);
+        // Masks are mostly empty: if no bit is set in any row the erosion windows of this workgroup touch, the
+        // eroded rows are zero (an image row never erodes to more than it holds) -- one pass over the source
+        // words instead of ero_k x 3 loads per eroded word (4K, 7 x 7: 960 loads instead of 12 600 per workgroup).
+        const int ya = max(r0 - ero_k / 2, 0), yb = min(r0 + (4 + dk - 1) - ero_k / 2 + ero_k - 1, g.H);   // source rows [ya, yb)
+        u64 seen = 0ull;
+        for (int i = ya * g.words + threadIdx.x; i < yb * g.words; i += 256) seen |= src_img[i];
+        if (__syncthreads_or(seen != 0ull)) {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int rr = i / g.words, w = i - rr * g.words;
+                const int yy = r0 + rr;
+                er[i] = (yy < 0 || yy >= g.H) ? 0ull : erode_word(g, src_img, yy, w, ero_k);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) er[i] = 0ull;
         }
         __syncthreads();
     }
