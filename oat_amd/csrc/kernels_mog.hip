@@ -308,7 +308,7 @@ struct Audit {
 // not bound by its second round trip but by the memory system (5.2 TB/s of real traffic on a device whose plain
 // copy reaches 6.6), and K1b added 50 us (profiles/r02_k1_split_rejected_kernel_trace.md).
 template <int CH, bool AUDIT>
-__global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     Audit<AUDIT> au;
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
@@ -359,9 +359,18 @@ __global__ __launch_bounds__(256, 8) void k_mog_fused(Geom g, MogLaunch a, int f
     auto ld_rec = [&](int k, float &v, float *m) {                  // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
         if (CH == 3) {
+            // (the default-policy load stays a HIP float4 load: as `*(const f32x4 *)rp` -- the ext-vector type the
+            // nontemporal builtin needs -- the traffic-audit instantiation of this kernel, and only it, updated
+            // the model wrongly and differently from run to run on ROCm 7.2; tools/state_check.py and
+            // test_long_run_model_parity_with_audited_steps catch that class of fault)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 q = k >= OATGPU_NTK ? __builtin_nontemporal_load((const f32x4 *)rp) : *(const f32x4 *)rp;
-            v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+            if (k >= OATGPU_NTK) {
+                const f32x4 q = __builtin_nontemporal_load((const f32x4 *)rp);
+                v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+            } else {
+                const float4 q = *(const float4 *)rp;
+                v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+            }
         } else {
             const float2 q = *(const float2 *)rp;
             v = q.x; m[0] = q.y;
