@@ -307,7 +307,7 @@ struct Audit {
 // mask, K1b takes them compacted) -- K1a alone ran no faster than the whole one-kernel form (92 us): the kernel is
 // not bound by its second round trip but by the memory system (5.2 TB/s of real traffic on a device whose plain
 // copy reaches 6.6), and K1b added 50 us (profiles/r02_k1_split_rejected_kernel_trace.md).
-template <int CH, bool AUDIT>
+template <int CH, bool AUDIT, bool NTLD>
 __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     Audit<AUDIT> au;
@@ -337,15 +337,16 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
     const unsigned voff_w = p * 4u, voff_r = p * 4u * (1 + CH);     // a stream's model stays below 4 GiB (oatgpu_create)
 #define SW(k) ((unsigned)(k) * ((2 + CH) * PA4 + 8u * (unsigned)kPlanePad))
 #define SR(k) (SW(k) + PA4 + 4u * (unsigned)kPlanePad)
-// Modes >= OATGPU_NTK are accessed with the streaming (nontemporal) cache policy: slots 1..4 are touched by a few
-// per cent of the pixels of an everyday model (nothing worth keeping in the caches), and on a dense model everything
-// streams.  Measured (r02, gpurun ab21): dense 4K 306 -> 295 us, sparse unchanged; mode 0 too (NTK = 0): sparse
-// unchanged, dense 293 / 332 us in two runs -- mode 0 keeps the default policy.
-#ifndef OATGPU_NTK
-#define OATGPU_NTK 1
-#endif
-#define LDW(k) __builtin_bit_cast(float, (k) >= OATGPU_NTK ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
-#define STW(k, v) do { if ((k) >= OATGPU_NTK) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 2); \
+// Cache policy of slots 1..4 (r02, tools/pmc_ab.sh on one box, 4K):
+//   stores nontemporal, always: nothing changes on an everyday model (100.7 us, 52.3 B/px moved -- as without), a
+//     dense model gains 2.6 %;
+//   loads nontemporal too (NTLD, chosen per launch): a dense model gains another 6 % (sustained 339 -> 318 us:
+//     everything streams, nothing is worth a cache line), an everyday model LOSES 5 % and moves 56 instead of 52 B/px
+//     (the second mode of a flickering pixel and the weights of live slots ARE re-read next frame).  The host picks
+//     NTLD from the model's density, which a sampling kernel measures every 64 frames (k_density_probe).
+//   Mode 0 keeps the default policy either way.
+#define LDW(k) __builtin_bit_cast(float, (NTLD && (k) >= 1) ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
+#define STW(k, v) do { if ((k) >= 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 2); \
                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 0); } while (0)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
             // the model wrongly and differently from run to run on ROCm 7.2; tools/state_check.py and
             // test_long_run_model_parity_with_audited_steps catch that class of fault)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            if (k >= OATGPU_NTK) {
+            if (NTLD && k >= 1) {
                 const f32x4 q = __builtin_nontemporal_load((const f32x4 *)rp);
                 v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
             } else {
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
             u32x4 q;
             q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
             q.z = __builtin_bit_cast(unsigned, m[1]); q.w = __builtin_bit_cast(unsigned, m[2]);
-            if (k >= OATGPU_NTK) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
+            if (k >= 1) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
             else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
         } else {
             u32x2 q;
@@ -557,22 +558,54 @@ void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 
-template <int CH, bool AUDIT>
+template <int CH, bool AUDIT, bool NTLD>
 static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT>), grid, dim3(256), 0, st, g, a, first_stream);
+    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD>), grid, dim3(256), 0, st, g, a, first_stream);
 }
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
-    if (a.audit) {
-        if (a.channels == 1) launch_mog_ch<1, true>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, true>(g, a, first_stream, n_streams, st);
+    if (a.audit) {                       // (the audit counts bytes, not cache behaviour: default-policy loads)
+        if (a.channels == 1) launch_mog_ch<1, true, false>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, true, false>(g, a, first_stream, n_streams, st);
+    } else if (a.nt_loads) {
+        if (a.channels == 1) launch_mog_ch<1, false, true>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, false, true>(g, a, first_stream, n_streams, st);
     } else {
-        if (a.channels == 1) launch_mog_ch<1, false>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, false>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, false, false>(g, a, first_stream, n_streams, st);
     }
+}
+
+// Model density for the cache-policy choice: ONE workgroup samples 16 384 counter bytes of a coarse lattice over
+// all streams and stores {sum of LIVE modes (1 + live hints), samples} to `out` (host-mapped; the host reads it
+// whenever it next launches a probe -- a hint, never waited for; plain stores, no atomics on host memory).
+__global__ __launch_bounds__(1024) void k_density_probe(const uint8_t *nmodes, size_t total, size_t stride, unsigned *out)
+{
+    __shared__ unsigned red[2][16];
+    unsigned live = 0, n = 0;
+    for (size_t j = threadIdx.x; j * stride < total; j += 1024) {
+        const unsigned c = nmodes[j * stride];
+        if (c & kCountMask) { live += 1u + (unsigned)__popc((c >> (kLiveShift + 1)) & 0xfu); n += 1; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { live += __shfl_xor(live, o); n += __shfl_xor(n, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = live; red[1][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned a = 0, b = 0;
+        for (int i = 0; i < 16; ++i) { a += red[0][i]; b += red[1][i]; }
+        out[0] = a;
+        out[1] = b;
+    }
+}
+void launch_density_probe(const uint8_t *nmodes, size_t total, unsigned *out, hipStream_t st)
+{
+    const size_t samples = 16384;
+    const size_t stride = total > samples ? total / samples : 1;
+    hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(1024), 0, st, nmodes, total, stride, out);
 }
 
 // ------------------------------------------------------------ small kernels --

@@ -54,6 +54,11 @@ struct oatgpu_ctx {
                                                   // overlapped with later frames' per-pixel kernels and each other
     hipEvent_t ev_k1[kNB] = {};    // the K1 whose back half runs on B[q] has finished (its threshold bits are ready)
     unsigned long long enq_total = 0, col_total = 0;  // pipelined frames enqueued / collected so far
+    // cache policy of K1's slot-1..4 loads (kernels_mog.hip): streaming on dense models.  Two host-mapped
+    // {live modes, samples} pairs filled alternately by k_density_probe; read one probe late, never waited for.
+    unsigned *dens_host = nullptr, *dens_dev = nullptr;
+    unsigned long long dens_probes = 0;
+    bool nt_loads = false;
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
     hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
@@ -290,6 +295,7 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.roots); hipFree(b.nroots);
     }
     if (c->res_host) hipHostFree(c->res_host);
+    if (c->dens_host) hipHostFree(c->dens_host);
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
     }
@@ -410,6 +416,9 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
     if (ok && hipHostGetDevicePointer((void **)&c->res_dev, c->res_host, 0) != hipSuccess) ok = false;
+    if (ok && hipHostMalloc((void **)&c->dens_host, 4 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) ok = false;
+    if (ok && hipHostGetDevicePointer((void **)&c->dens_dev, c->dens_host, 0) != hipSuccess) ok = false;
+    if (ok) memset(c->dens_host, 0, 4 * sizeof(unsigned));
     if (ok) {
         c->ring_ev.resize(c->ring_slots);
         c->back_graph.assign(c->ring_slots, nullptr);
@@ -545,7 +554,7 @@ static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rat
     MogLaunch a{};
     a.frames = frames; a.channels = c->cfg.channels; a.state = c->state; a.nmodes = c->nmodes; a.thr_bits = thr_buf(c, 0);
     a.out_bgr = nullptr; a.out_mask = nullptr; a.out_base = 0; a.roi_bits = c->roi;
-    a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh;
+    a.alphaT = r.alphaT; a.alpha1 = r.alpha1; a.prune = r.prune; a.fresh = r.fresh; a.nt_loads = c->nt_loads ? 1 : 0;
     a.mp = mogparams_of(c->cfg);
     a.rp = range_of(c->cfg);
     a.audit = c->audit_on ? c->audit_dev : nullptr;
@@ -972,6 +981,17 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     }
     HIPCHK(c, hipGetLastError());
     if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
+    {   // model density -> cache policy of the next launches: probes at frames 8, 16, 32, then every 64th; each
+        // probe's numbers are read when the NEXT one is launched (it finished long ago: the ring is a few deep)
+        const unsigned long long t = c->enq_total;
+        if ((t >= 8 && t < 64 && (t & (t - 1)) == 0) || (t >= 64 && (t & 63) == 0)) {
+            const int ds = (int)(c->dens_probes & 1);
+            const unsigned *prev = c->dens_host + 2 * (ds ^ 1);
+            if (c->dens_probes && prev[1]) c->nt_loads = 2ull * prev[0] >= 5ull * prev[1];      // mean live modes >= 2.5
+            launch_density_probe(c->nmodes, (size_t)n * c->g.Palloc, c->dens_dev + 2 * ds, A);
+            c->dens_probes++;
+        }
+    }
     if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
         HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
         c->enq_total++;

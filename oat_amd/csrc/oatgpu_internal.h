@@ -88,6 +88,7 @@ struct MogLaunch {
     const u64 *roi_bits;     // [n][Palloc/64] region-of-interest bits (framefilt mask fused in) or nullptr
     float alphaT, alpha1, prune;
     int fresh;               // 1: model is (re)initialised this frame -> no modes
+    int nt_loads;            // 1: slots 1..4 are LOADED with the streaming cache policy too (dense models; kernels_mog.hip)
     unsigned long long *audit;   // nullptr, or 8 device counters: the traffic-audit instantiation runs (oatgpu_traffic_audit)
     MogParams mp;
     RangeParams rp;
@@ -98,6 +99,7 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n
 // plain streaming kernels for the achievable-bandwidth measurement (n16 = number of 16-byte elements)
 void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st);
 void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);
+void launch_density_probe(const uint8_t *nmodes, size_t total, unsigned *out, hipStream_t st);   // out = {live modes, samples}
 void launch_nop(hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
 void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
 // 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.

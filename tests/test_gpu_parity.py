@@ -1047,3 +1047,6 @@ def test_long_run_model_parity_with_audited_steps(A):
     msgs = []
     assert state_check.run(1080, 1920, 120, 24, audited=6, log=msgs.append) == 0, msgs
     assert state_check.run(480, 640, 90, 16, streams=3, audited=4, log=msgs.append) == 0, msgs
+    # a dense model (five live modes everywhere): from its second density probe on the library runs the instantiation
+    # whose slot-1..4 loads use the streaming cache policy -- same numbers
+    assert state_check.run(480, 640, 100, 10, streams=2, audited=4, dense=True, log=msgs.append) == 0, msgs

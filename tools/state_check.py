@@ -17,12 +17,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, log=print):
+def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False, log=print):
     import oat_amd
     import oracle_lib as O
     from oat_amd.synth import SyntheticStream, disc_hsv_window
-    st = [SyntheticStream(rows, cols, s, n_discs=2) for s in range(streams)]
-    fr = [[st[s].frame(9 * t, with_discs=t > 0) for s in range(streams)] for t in range(pool)]
+    if dense:
+        # bench.py's dense model: every pixel cycles through five well separated colours (own phase per pixel) --
+        # five live modes everywhere, the library switches the slot-1..4 loads to the streaming cache policy
+        # (the NTLD instantiation of the per-pixel kernel) after its first density probes
+        rng = np.random.default_rng(0xD0)
+        table = np.array([[20, 30, 40], [90, 200, 60], [200, 60, 120], [240, 240, 230], [40, 130, 220]], np.int16)
+        phase = rng.integers(0, 5, (streams, rows, cols))
+        pool = max(5, pool // 5 * 5)
+        fr = [[np.clip(table[(phase[s] + t) % 5] + rng.integers(-5, 6, (rows, cols, 3)), 0, 255).astype(np.uint8)
+               for s in range(streams)] for t in range(pool)]
+    else:
+        st = [SyntheticStream(rows, cols, s, n_discs=2) for s in range(streams)]
+        fr = [[st[s].frame(9 * t, with_discs=t > 0) for s in range(streams)] for t in range(pool)]
     hp = oat_amd.HotPath(rows, cols, n_streams=streams, adaptation_coeff=alpha, erode=3, dilate=7,
                          area=(20.0, 1e5), ring_depth=4, **disc_hsv_window())
     got = []
@@ -74,5 +85,6 @@ if __name__ == "__main__":
     ap.add_argument("--pool", type=int, default=24)
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--audited", type=int, default=6)
+    ap.add_argument("--dense", action="store_true")
     a = ap.parse_args()
-    sys.exit(1 if run(a.rows, a.cols, a.frames, a.pool, streams=a.streams, audited=a.audited) else 0)
+    sys.exit(1 if run(a.rows, a.cols, a.frames, a.pool, streams=a.streams, audited=a.audited, dense=a.dense) else 0)
