@@ -164,7 +164,7 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // x of the run entering every word, and initialises the union-find at run heads.
 template <bool ERODE>
 __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                 int first_stream)
+                                                 int first_stream, int clear_lds_ok)
 {
     extern __shared__ u64 er[];
     const int lane = threadIdx.x & 63;
@@ -201,12 +201,15 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     int *carry = b.carry + (size_t)s * g.H * g.words + (size_t)y * g.words;
     int *parent = b.parent + (size_t)s * g.Palloc;
 
-    if (y == 0 && lane == 0) b.nroots[s] = 0u;
+    if (y == 0 && lane == 0) { b.nroots[s] = 0u; if (clear_lds_ok) b.lds_ok[s] = 0u; }
 
     const bool frame_row = (y == 0) || (y == g.H - 1);
     const int lastx = g.W - 1;
     int chunk_carry = 0;        // start x of the last run seen so far
     u64 chunk_prevbit = 0;      // pixel value just left of this chunk
+    unsigned short *wpre = b.wpre + ((size_t)s * g.H + y) * g.words;
+    unsigned runs_before = 0;   // run starts of this row in earlier chunks
+    bool row_fg = false;
 
     for (int c0 = 0; c0 < g.words; c0 += 64) {
         const int w = c0 + lane;
@@ -241,11 +244,22 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
         const u64 Tp = __shfl(T, pl);
         const int cin = lower ? ((c0 + pl) * 64 + msb64(Tp)) : chunk_carry;
 
+        // run starts in the words before this one (k_blob_lds places a row's runs with it)
+        const unsigned cntT = (unsigned)__popcll(T);
+        unsigned incl = cntT;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
         if (active) {
             fin[w] = F;
             trans[w] = T;
             carry[w] = cin;
+            wpre[w] = (unsigned short)min(runs_before + incl - cntT, 65535u);
         }
+        runs_before += __shfl(incl, 63);
+        row_fg = row_fg || __ballot(F != 0ull) != 0ull;
         // carry state into the next chunk (all lanes agree)
         if (nz) {
             const int hl = msb64(nz);
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     // belong to the OUTSIDE component: hang them under root 0 right away -- on ordinary frames
     // this removes the H-long merge chain of full-width background runs.  Foreground run heads
     // get their Green accumulators cleared here.
+    if (lane == 0) b.rowinfo[(size_t)s * g.H + y] = row_fg ? (int)runs_before : 0;
     const int last_start = chunk_carry;          // start x of the row's last run
     long long *acc = b.acc + (size_t)s * g.Palloc * 3;
     for (int c0 = 0; c0 < g.words; c0 += 64) {
@@ -340,6 +355,7 @@ __global__ __launch_bounds__(256) void k_merge(Geom g, BlobBuffers b, int first_
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (g.H - 1) * g.words) return;
     const int s = first_stream + blockIdx.y;
+    if (b.lds_ok[s]) return;                       // k_blob_lds took this frame
     const int y = 1 + t / g.words, w = t % g.words;
     const size_t soff = (size_t)s * (g.Palloc >> 6);
     const u64 *fin = b.fin + soff;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(kGreenBlock) void k_green_select(Geom g, BlobBuffer
     const int t = tt / kGreenChunks;
     const u64 chunk_bits = (kGreenChunks == 1 ? ~0ull : ((1ull << (64 / kGreenChunks)) - 1ull)) << ((tt % kGreenChunks) * (64 / kGreenChunks));
     const int s = first_stream + blockIdx.y;
+    if (b.lds_ok[s]) return;                       // k_blob_lds took this frame (uniform over the workgroup)
     const size_t soff = (size_t)s * (g.Palloc >> 6);
     const u64 *fin = b.fin + soff;
     const u64 *trans = b.trans + soff;
@@ -576,20 +593,360 @@ __global__ __launch_bounds__(kGreenBlock) void k_green_select(Geom g, BlobBuffer
     }
 }
 
+// ------------------------------------------------------------ K4'/K5': one workgroup, in LDS ----
+// Masks are mostly empty: after morphology a frame holds a few blobs, i.e. a few hundred "dirty" rows with three to
+// five runs each.  Then ONE workgroup per stream does what k_merge + k_green_select do, on a run list in LDS: every
+// dependent step of the union-find is an LDS access (~40 ns) instead of an L2 atomic (~270 ns, tools/atomic_latency.hip),
+// and the three launches with their drain/fill become one.  k_rowscan supplies, per row, whether it holds foreground and
+// how many runs (rowinfo), and per word the run starts before it (wpre).  Runs of a row alternate background /
+// foreground starting with background (column 0 is zeroed), so run k of a row is foreground iff k is odd.
+//   nodes: 0 = OUTSIDE; 1..R = the runs of the dirty rows in raster order (so the smallest node of a component is its
+//   first pixel, the reference's tie-break key -- as in the global kernels).
+//   A background run is OUTSIDE if it is the first or the last of its row, or if the row above or below is not dirty
+//   (an all-background row is outside as a whole: both its ends are); otherwise it joins the background runs it
+//   overlaps in the row above (4-connected).  Foreground runs join the foreground runs of the row above they touch
+//   (8-connected: overlap widened by one pixel).
+// Falls back (lds_ok = 0: k_merge + k_green_select take the frame) when the frame has more than kLdsRows dirty rows,
+// kLdsRuns runs or kLdsRoots foreground components.
+constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768, kLdsBlock = 1024;      // 58 KB of LDS
+
+__device__ __forceinline__ int lds_find(int *par, int i)
+{
+    int cur = i, p = par[cur];
+    while (p != cur) {
+        const int gp = par[p];
+        if (gp != p) atomicMin(&par[cur], gp);
+        cur = p;
+        p = gp;
+    }
+    return cur;
+}
+__device__ __forceinline__ void lds_union(int *par, int a, int b)
+{
+    for (;;) {
+        a = lds_find(par, a);
+        b = lds_find(par, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, double min_area, double max_area,
+                                                        ResultRec *results, int first_stream, int spec)
+{
+    __shared__ unsigned short rows[kLdsRows + 1];        // dirty row r -> image row
+    __shared__ unsigned rptr[kLdsRows + 2];              // dirty row r -> its first node
+    __shared__ unsigned short rstart[kLdsRuns + 2];      // node -> start x
+    __shared__ unsigned short rrow[kLdsRuns + 2];        // node -> dirty row
+    __shared__ int par[kLdsRuns + 2];
+    __shared__ unsigned short rootslot[kLdsRuns + 2];
+    __shared__ int rootnode[kLdsRoots];
+    __shared__ unsigned long long acc[kLdsRoots * 3];
+    __shared__ unsigned scan_d[16], scan_r[16];
+    __shared__ unsigned nroots_s;
+    __shared__ unsigned long long red[kLdsBlock / 64];
+
+    const int s = first_stream + blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t soff = (size_t)s * (g.Palloc >> 6);
+    const u64 *fin = b.fin + soff;
+    const u64 *trans = b.trans + soff;
+    const unsigned short *wpre = b.wpre + (size_t)s * g.H * g.words;
+    const int *rowinfo = b.rowinfo + (size_t)s * g.H;
+
+#ifdef OATGPU_LDS_TIMING
+    long long tk[8]; int tn = 0;
+#define TK() tk[tn++] = wall_clock64()
+#else
+#define TK()
+#endif
+    TK();
+    // ---- A: dirty rows and their run counts, in order (each thread owns a stretch of consecutive rows) ----
+    const int per = (g.H + kLdsBlock - 1) / kLdsBlock;
+    const int y0 = t * per, y1 = min(y0 + per, g.H);
+    unsigned d = 0, rn = 0;
+    for (int y = y0; y < y1; ++y) { const int ri = rowinfo[y]; if (ri) { d++; rn += (unsigned)ri; } }
+    unsigned di = d, ri_ = rn;                          // inclusive scans over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned vd = __shfl_up(di, o), vr = __shfl_up(ri_, o);
+        if (lane >= o) { di += vd; ri_ += vr; }
+    }
+    if (lane == 63) { scan_d[wave] = di; scan_r[wave] = ri_; }
+    if (t == 0) nroots_s = 0;
+    __syncthreads();
+    unsigned dbase = di - d, rbase = ri_ - rn, D = 0, R = 0;
+    for (int i = 0; i < kLdsBlock / 64; ++i) {
+        if (i < wave) { dbase += scan_d[i]; rbase += scan_r[i]; }
+        D += scan_d[i]; R += scan_r[i];
+    }
+    if (D > (unsigned)kLdsRows || R > (unsigned)kLdsRuns) {          // too busy a frame for this path
+        if (t == 0) {
+            b.lds_ok[s] = 0u;
+            if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; results[s] = r; }
+        }
+        return;
+    }
+    if (D == 0) {                                                     // nothing in the frame
+        if (t == 0) {
+            ResultRec r{};
+            r.first_pixel = -1;
+            r.path = 1;
+            results[s] = r;
+            b.lds_ok[s] = 1u;
+        }
+        return;
+    }
+    for (int y = y0; y < y1; ++y) {
+        const int ri = rowinfo[y];
+        if (ri) { rows[dbase] = (unsigned short)y; rptr[dbase] = 1u + rbase; dbase++; rbase += (unsigned)ri; }
+    }
+    if (t == 0) { rptr[D] = 1u + R; par[0] = 0; }
+    __syncthreads();
+
+    TK();
+    // ---- B: the run list ----
+    for (unsigned i = t; i < D * (unsigned)g.words; i += kLdsBlock) {
+        const unsigned r = i / (unsigned)g.words, w = i - r * (unsigned)g.words;
+        const size_t gi = (size_t)rows[r] * g.words + w;
+        u64 T = trans[gi];
+        if (T) {
+            unsigned node = rptr[r] + wpre[gi];
+            while (T) {
+                const int bit = lsb64(T);
+                T &= T - 1;
+                rstart[node] = (unsigned short)(w * 64u + (unsigned)bit);
+                rrow[node] = (unsigned short)r;
+                par[node] = (int)node;
+                node++;
+            }
+        }
+    }
+    __syncthreads();
+
+    TK();
+    // ---- C: unions ----
+    for (unsigned i = 1 + t; i <= R; i += kLdsBlock) {
+        const unsigned r = rrow[i], k = i - rptr[r];
+        const int y = rows[r];
+        const int sx = rstart[i], ex = (i + 1 < rptr[r + 1]) ? (int)rstart[i + 1] - 1 : g.W - 1;
+        const bool adj_up = r > 0 && rows[r - 1] == y - 1, adj_dn = r + 1 < D && rows[r + 1] == y + 1;
+        if (!(k & 1u)) {
+            if (k == 0 || i + 1 == rptr[r + 1] || !adj_up || !adj_dn) lds_union(par, (int)i, 0);
+            if (adj_up) {
+                const unsigned je = rptr[r];
+                for (unsigned j = rptr[r - 1]; j < je; j += 2) {
+                    const int sj = rstart[j];
+                    if (sj > ex) break;
+                    const int ej = (j + 1 < je) ? (int)rstart[j + 1] - 1 : g.W - 1;
+                    if (ej >= sx) lds_union(par, (int)i, (int)j);
+                }
+            }
+        } else if (adj_up) {
+            const unsigned je = rptr[r];
+            for (unsigned j = rptr[r - 1] + 1; j < je; j += 2) {
+                const int sj = rstart[j];
+                if (sj > ex + 1) break;
+                const int ej = (j + 1 < je) ? (int)rstart[j + 1] - 1 : g.W - 1;
+                if (ej >= sx - 1) lds_union(par, (int)i, (int)j);
+            }
+        }
+    }
+    __syncthreads();
+
+    TK();
+    // ---- D: flatten; foreground roots get an accumulator slot ----
+    int myroot[(kLdsRuns + kLdsBlock) / kLdsBlock];
+#pragma unroll
+    for (int q = 0; q < (kLdsRuns + kLdsBlock) / kLdsBlock; ++q) {
+        const unsigned i = 1 + t + q * kLdsBlock;
+        myroot[q] = i <= R ? lds_find(par, (int)i) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (kLdsRuns + kLdsBlock) / kLdsBlock; ++q) {
+        const unsigned i = 1 + t + q * kLdsBlock;
+        if (i <= R) {
+            par[i] = myroot[q];
+            if (myroot[q] == (int)i && ((i - rptr[rrow[i]]) & 1u)) {
+                const unsigned slot = atomicAdd(&nroots_s, 1u);
+                if (slot < (unsigned)kLdsRoots) {
+                    rootslot[i] = (unsigned short)slot;
+                    rootnode[slot] = (int)i;
+                    acc[slot * 3] = 0ull; acc[slot * 3 + 1] = 0ull; acc[slot * 3 + 2] = 0ull;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned NR = nroots_s;
+    if (NR > (unsigned)kLdsRoots) {
+        if (t == 0) {
+            b.lds_ok[s] = 0u;
+            if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; results[s] = r; }
+        }
+        return;
+    }
+
+    TK();
+    // ---- E: Green sums over the edges facing OUTSIDE background: four threads per foreground run, thread q of the
+    // four taking bits 16q..16q+15 of every word (the per-bit loop is serial, and the top and bottom rows of a blob
+    // are all border) ----
+    const u64 qbits = 0xffffull << (16 * (t & 3));
+    for (unsigned i0 = (unsigned)(t >> 2); i0 < R; i0 += kLdsBlock / 4) {
+        const unsigned i = 1 + i0;
+        const unsigned r = rrow[i], k = i - rptr[r];
+        if (!(k & 1u)) continue;
+        const int y = rows[r];
+        const int sx = rstart[i], ex = (int)rstart[i + 1] - 1;       // a foreground run is never the last of its row
+        const bool adj_up = r > 0 && rows[r - 1] == y - 1, adj_dn = r + 1 < D && rows[r + 1] == y + 1;
+        const bool out_l = par[i - 1] == 0, out_r = par[i + 1] == 0;
+        // run of row rr (a dirty neighbour row) that holds pixel x, memoised: [lo, hi] = its extent, root = its root
+        struct Memo { int lo, hi, root; unsigned at; };
+        Memo mu{1, 0, 0, adj_up ? rptr[r - 1] : 0u}, md{1, 0, 0, adj_dn ? rptr[r + 1] : 0u};
+        auto root_at = [&](Memo &m, unsigned rr, int x) -> int {
+            if (x >= m.lo && x <= m.hi) return m.root;
+            unsigned j = (x > m.hi) ? m.at : rptr[rr];                // runs are visited left to right
+            const unsigned je = rptr[rr + 1];
+            while (j + 1 < je && (int)rstart[j + 1] <= x) ++j;
+            m.at = j; m.lo = rstart[j]; m.hi = (j + 1 < je) ? (int)rstart[j + 1] - 1 : g.W - 1; m.root = par[j];
+            return m.root;
+        };
+        long long s00 = 0, s10 = 0, s01 = 0;
+        const size_t rc = (size_t)y * g.words, ru = rc - g.words, rd = rc + g.words;
+        for (int w = sx >> 6; w <= (ex >> 6); ++w) {
+            const int lo = max(sx - w * 64, 0), hi = min(ex - w * 64, 63);
+            const u64 runbits = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull) & qbits;
+            if (!runbits) continue;                                  // nothing of the run in this thread's bits
+            const u64 cur = fin[rc + w];
+            const bool hp = w > 0, hn = w + 1 < g.words;
+            const u64 U = fin[ru + w], Dn = fin[rd + w];
+            const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
+            const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
+            const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
+            const u64 L = (cur << 1) | (curP >> 63), Rr = (cur >> 1) | (curN << 63);
+            const u64 UL = (U << 1) | (upP >> 63), UR = (U >> 1) | (upN << 63);
+            const u64 DL = (Dn << 1) | (dnP >> 63), DR = (Dn >> 1) | (dnN << 63);
+            u64 cand = cur & ~(L & Rr & U & Dn) & runbits;
+            while (cand) {
+                const int bi = lsb64(cand);
+                cand &= cand - 1;
+                const int x = w * 64 + bi;
+                const u64 bit = 1ull << bi;
+                int qx, qy;
+                bool e;
+#define OAT_EDGE()  /* (qx, qy) is a neighbour of (x, y): |d| <= x + y < 2^15 (frames up to 16383 x 16383 take this path), the products fit 32 bits */ \
+                if (e) {                                                                      \
+                    const int dd = x * qy - qx * y;                                           \
+                    s00 += dd; s10 += dd * (x + qx); s01 += dd * (y + qy);                    \
+                }
+                if (!(L & bit) && out_l) {                                                    // left
+                    e = true;
+                    if (DL & bit) { qx = x - 1; qy = y + 1; } else if (Dn & bit) { qx = x; qy = y + 1; } else e = false;
+                    OAT_EDGE()
+                }
+                if (!(Dn & bit) && (!adj_dn || root_at(md, r + 1, x) == 0)) {                 // bottom
+                    e = true;
+                    if (DR & bit) { qx = x + 1; qy = y + 1; } else if (Rr & bit) { qx = x + 1; qy = y; } else e = false;
+                    OAT_EDGE()
+                }
+                if (!(Rr & bit) && out_r) {                                                   // right
+                    e = true;
+                    if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
+                    OAT_EDGE()
+                }
+                if (!(U & bit) && (!adj_up || root_at(mu, r - 1, x) == 0)) {                  // top
+                    e = true;
+                    if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
+                    OAT_EDGE()
+                }
+#undef OAT_EDGE
+            }
+        }
+        if (s00 | s10 | s01) {
+            const unsigned slot = rootslot[par[i]];
+            atomicAdd(&acc[slot * 3], (unsigned long long)s00);
+            atomicAdd(&acc[slot * 3 + 1], (unsigned long long)s10);
+            atomicAdd(&acc[slot * 3 + 2], (unsigned long long)s01);
+        }
+    }
+    __syncthreads();
+
+    TK();
+    // ---- F: the largest area in the window; ties go to the later first pixel (k_green_select's rule) ----
+    unsigned long long best = 0ull;
+    for (unsigned q = t; q < NR; q += kLdsBlock) {
+        const long long a00 = (long long)acc[q * 3];
+        if (a00 == 0) continue;
+        const u64 mag = (u64)(a00 < 0 ? -a00 : a00);
+        const double area = (double)mag * 0.5;
+        if (area >= min_area && area < max_area) {
+            const int node = rootnode[q];
+            const unsigned h = (unsigned)rows[rrow[node]] * (unsigned)g.Wp + (unsigned)rstart[node];
+            const unsigned long long key = (mag << 32) | (u64)h;
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long v = __shfl_xor(best, o);
+        best = v > best ? v : best;
+    }
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (t == 0) {
+        u64 key = 0ull;
+        for (int i = 0; i < kLdsBlock / 64; ++i) key = red[i] > key ? red[i] : key;
+        ResultRec r{};
+        r.first_pixel = -1;
+        r.path = 1;
+        if (key) {
+            const unsigned h = (unsigned)(key & 0xffffffffull);
+            // the root's slot: find it again (few roots)
+            for (unsigned q = 0; q < NR; ++q) {
+                const int node = rootnode[q];
+                if ((unsigned)rows[rrow[node]] * (unsigned)g.Wp + (unsigned)rstart[node] == h) {
+                    r.a00 = (long long)acc[q * 3]; r.a10 = (long long)acc[q * 3 + 1]; r.a01 = (long long)acc[q * 3 + 2];
+                    break;
+                }
+            }
+            const int yy = (int)(h / (unsigned)g.Wp), xx = (int)(h - (unsigned)yy * (unsigned)g.Wp);
+            r.first_pixel = yy * g.W + xx;
+            r.valid = 1;
+        }
+        results[s] = r;
+        b.lds_ok[s] = 1u;
+#ifdef OATGPU_LDS_TIMING
+        TK();
+        printf("lds D=%u R=%u NR=%u  A %lld B %lld C %lld D %lld E %lld F %lld (x10 ns)\n", D, R, NR, tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4], tk[6]-tk[5]);
+#endif
+    }
+}
+
 size_t rowscan_lds_bytes(const Geom &g, int dil_k)
 {
     return (size_t)(4 + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64);
 }
 
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st)
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode)
 {
+    const bool lds_able = g.H > 2 && g.H <= 16383 && g.W <= 16383;
+    if (mode == kBlobSpec && !lds_able) mode = kBlobFull;
+    const int clear = mode == kBlobGlobal || !lds_able;          // nobody else resets lds_ok then
     if (ero_k > 1)
         hipLaunchKernelGGL(k_rowscan<true>, dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
-                           st, g, src_bits, ero_k, dil_k, b, first_stream);
+                           st, g, src_bits, ero_k, dil_k, b, first_stream, clear);
     else
         hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
-                           dil_k, b, first_stream);
+                           dil_k, b, first_stream, clear);
+    if (lds_able && mode != kBlobGlobal)
+        hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, min_area, max_area, results,
+                           first_stream, mode == kBlobSpec ? 1 : 0);
+    if (mode == kBlobSpec) return;
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);

@@ -59,6 +59,13 @@ struct oatgpu_ctx {
     unsigned *dens_host = nullptr, *dens_dev = nullptr;
     unsigned long long dens_probes = 0;
     bool nt_loads = false;
+    // back half: frames go through row scan + k_blob_lds ONLY (kBlobSpec) while that keeps working; a frame too busy
+    // for the LDS kernel comes back marked, oatgpu_track_collect then runs the global kernels on its threshold bits
+    // (still in its ring slot) before handing the result out, and the full launch sequence is used until
+    // kSpecAfter frames in a row were taken by the LDS kernel again.
+    bool lds_spec = true;
+    int lds_streak = 0;
+    std::vector<char> slot_spec, slot_q;      // per ring slot: launched speculatively? which scratch set / B stream?
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
     hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
@@ -292,7 +299,7 @@ static void free_all(oatgpu_ctx *c)
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
-        hipFree(b.roots); hipFree(b.nroots);
+        hipFree(b.roots); hipFree(b.nroots); hipFree(b.wpre); hipFree(b.rowinfo); hipFree(b.lds_ok);
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
@@ -411,6 +418,9 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         A((void **)&b.done, n * sizeof(unsigned));
         A((void **)&b.roots, n * (PA / 2) * sizeof(int));
         A((void **)&b.nroots, n * sizeof(unsigned));
+        A((void **)&b.wpre, n * (size_t)g.H * g.words * sizeof(unsigned short));
+        A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
+        A((void **)&b.lds_ok, n * sizeof(unsigned));
     }
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
@@ -423,6 +433,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         c->ring_ev.resize(c->ring_slots);
         c->back_graph.assign(c->ring_slots, nullptr);
         c->slot_filtered.assign(c->ring_slots, 0);
+        c->slot_spec.assign(c->ring_slots + 1, 0);
+        c->slot_q.assign(c->ring_slots + 1, 0);
         for (auto &e : c->ring_ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming | ((c->expt & 8) ? hipEventDisableSystemFence : 0)) != hipSuccess) ok = false;
     }
@@ -434,6 +446,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         BlobBuffers &b = c->bb[q];
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+        if (ok && hipMemsetAsync(b.lds_ok, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
@@ -783,7 +796,7 @@ static void apply_kalman(const ResultRec &r, oatgpu_position *o)
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
 // the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
 static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int n, int slot, hipStream_t st,
-                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1)
+                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1, int mode = kBlobFull)
 {
     const Geom &g = c->g;
     const u64 *src = thr;
@@ -800,7 +813,7 @@ static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int
     c->last_morph = (dil || ero) ? bb.morph : src;
     c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st);
+    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st, mode);
     HIPCHK(c, hipGetLastError());
     return OATGPU_OK;
 }
@@ -1015,7 +1028,10 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
         c->last_fin = c->bb[q].fin;
     } else {
         if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
-        int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, ps ? ps->e[3] : nullptr);
+        const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;   // (the position filter is sequential: no repairs behind it)
+        c->slot_spec[slot] = mode == kBlobSpec;
+        c->slot_q[slot] = (char)q;
+        int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, ps ? ps->e[3] : nullptr, -1, -1, mode);
         if (rc) return rc;
     }
     if (c->kal_on) {
@@ -1040,6 +1056,30 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
     HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
+    {   // speculation bookkeeping (see lds_spec)
+        constexpr int kSpecAfter = 16;
+        bool all_lds = true, repair = false;
+        for (int s = 0; s < c->cfg.n_streams; ++s) {
+            if (r[s].valid == kNeedsGlobal) repair = true;
+            if (r[s].path != 1) all_lds = false;
+        }
+        if (repair) {
+            // the frame's threshold bits are still in its ring slot (a slot is reused only after this collect);
+            // its scratch set's stream runs the global kernels behind whatever later frame it is busy with
+            const int q = c->slot_q[slot];
+            hipStream_t B = c->serial ? c->stream : c->stream_b[q];
+            const int rc = back_half(c, c->bb[q], thr_buf(c, slot), 0, c->cfg.n_streams, slot, B, nullptr, -1, -1, kBlobGlobal);
+            if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(B));
+            c->lds_spec = false;
+            c->lds_streak = 0;
+        } else if (all_lds) {
+            if (++c->lds_streak >= kSpecAfter) c->lds_spec = true;
+        } else {
+            c->lds_streak = 0;
+            c->lds_spec = false;
+        }
+    }
     for (int s = 0; s < c->cfg.n_streams; ++s) {
         to_position(r[s], &out[s]);
         if (c->slot_filtered[slot]) apply_kalman(r[s], &out[s]);

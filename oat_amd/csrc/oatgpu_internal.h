@@ -139,6 +139,10 @@ struct BlobBuffers {
     unsigned *done;  // [n]            workgroup arrival counter of k_green_select
     int *roots;      // [n][Palloc/2]  foreground roots of the current frame
     unsigned *nroots;// [n]
+    // the single-workgroup LDS path (k_blob_lds): written by k_rowscan
+    unsigned short *wpre;  // [n][H*words] run starts of the row in the words before this one
+    int *rowinfo;          // [n][H]       0: no foreground in the row; else its number of runs
+    unsigned *lds_ok;      // [n]          1: k_blob_lds wrote this frame's result, k_merge / k_green_select stand down
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -146,7 +150,7 @@ struct ResultRec {   // device-side result, one per stream per step
     int valid;
     // written by k_kalman when the position filter is on
     int kal_valid;
-    int pad_;
+    int path;            // who wrote the record: 1 = k_blob_lds, 0 = k_green_select (host: when to speculate, below)
     double kx, ky, kvx, kvy;
 };
 
@@ -175,7 +179,14 @@ void launch_morph(const Geom &g, const u64 *src, u64 *dst, int k, bool is_erode,
 // results: device-visible (host-mapped) array indexed by stream.
 constexpr size_t kRowscanLdsMax = 64 * 1024;
 size_t rowscan_lds_bytes(const Geom &g, int dil_k);
+// mode: kBlobFull  = row scan + k_blob_lds + k_merge + k_green_select (the last two stand down when the LDS
+//                     kernel took the frame);
+//       kBlobSpec  = row scan + k_blob_lds only: a frame too busy for it comes back with valid == kNeedsGlobal and
+//                     the caller runs kBlobGlobal on the same threshold bits before it hands the result out;
+//       kBlobGlobal = row scan + k_merge + k_green_select.
+enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
+constexpr int kNeedsGlobal = -2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st);
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
 
 }  // namespace oatgpu

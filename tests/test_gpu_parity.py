@@ -1050,3 +1050,42 @@ def test_long_run_model_parity_with_audited_steps(A):
     # a dense model (five live modes everywhere): from its second density probe on the library runs the instantiation
     # whose slot-1..4 loads use the streaming cache policy -- same numbers
     assert state_check.run(480, 640, 100, 10, streams=2, audited=4, dense=True, log=msgs.append) == 0, msgs
+
+
+def test_back_half_speculation_and_repair(A):
+    """The pipelined path launches the row scan + the single-workgroup LDS blob kernel only, as long as frames are
+    sparse enough for it; a frame that is not (here: thousands of foreground specks) comes back marked and
+    oatgpu_track_collect runs the global kernels on its threshold bits before handing the result out.  Sparse and
+    busy frames alternate in every pattern the ring can see; every result must be the oracle's."""
+    rows, cols, n = 240, 320, 2
+    rng = np.random.default_rng(11)
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    hp = A.HotPath(rows, cols, n_streams=n, ring_depth=4, adaptation_coeff=0.01, erode=0, dilate=2, area=(4.0, 1e9), **win)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=0, dilate=2, min_area=4.0, max_area=1e9)
+    orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    base = rng.integers(90, 140, (n, rows, cols, 3)).astype(np.int16)
+
+    def frame(t, busy):
+        f = np.clip(base + rng.integers(-5, 6, base.shape), 0, 255).astype(np.uint8)
+        if t > 0:
+            for s in range(n):
+                cy, cx = 40 + (7 * t + 30 * s) % 150, 50 + (11 * t + 40 * s) % 200
+                f[s, cy:cy + 20, cx:cx + 25] = (255, 64, 0)
+                if busy:                                     # specks of the blob colour all over: > 3072 runs
+                    m = rng.random((rows, cols)) < 0.08
+                    f[s][m] = (255, 64, 0)
+        return f
+    pattern = [0] * 20 + [1, 0, 0, 1, 1, 0, 1, 1, 1, 1] + [0] * 24 + [1] + [0] * 5
+    frames = [frame(t, b) for t, b in enumerate(pattern)]
+    got = []
+    for f in frames:
+        hp.enqueue(list(f))
+        if hp.outstanding() >= 4:
+            got.append(hp.collect())
+    while hp.outstanding():
+        got.append(hp.collect())
+    assert len(got) == len(frames)
+    for t, f in enumerate(frames):
+        for s in range(n):
+            want = O.chain_step(orc[s], f[s], 0.01, p)[0]
+            _same_detection(got[t][s], want, (t, s, pattern[t]))
