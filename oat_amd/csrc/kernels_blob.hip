@@ -827,15 +827,23 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
             const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
             const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
             const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
-            const u64 L = (cur << 1) | (curP >> 63), Rr = (cur >> 1) | (curN << 63);
-            const u64 UL = (U << 1) | (upP >> 63), UR = (U >> 1) | (upN << 63);
-            const u64 DL = (Dn << 1) | (dnP >> 63), DR = (Dn >> 1) | (dnN << 63);
-            u64 cand = cur & ~(L & Rr & U & Dn) & runbits;
+            // this thread's 16 bits of the nine masks as 32-bit values: the per-bit loop below is what the kernel's
+            // time goes into (one compute unit runs it), and on 64-bit masks it was twice as many instructions
+            const int sh = 16 * (t & 3);
+            const u64 L64 = (cur << 1) | (curP >> 63), R64 = (cur >> 1) | (curN << 63);
+            const u64 UL64 = (U << 1) | (upP >> 63), UR64 = (U >> 1) | (upN << 63);
+            const u64 DL64 = (Dn << 1) | (dnP >> 63), DR64 = (Dn >> 1) | (dnN << 63);
+#define Q16(v) ((unsigned)((v) >> sh) & 0xffffu)
+            const unsigned cq = Q16(cur & runbits), Lq = Q16(L64), Rq = Q16(R64), Uq = Q16(U), Dq = Q16(Dn);
+            const unsigned ULq = Q16(UL64), URq = Q16(UR64), DLq = Q16(DL64), DRq = Q16(DR64);
+#undef Q16
+            unsigned cand = cq & ~(Lq & Rq & Uq & Dq);
+            const int xbase = w * 64 + sh;
             while (cand) {
-                const int bi = lsb64(cand);
-                cand &= cand - 1;
-                const int x = w * 64 + bi;
-                const u64 bit = 1ull << bi;
+                const int bi = __ffs((int)cand) - 1;
+                cand &= cand - 1u;
+                const int x = xbase + bi;
+                const unsigned bit = 1u << bi;
                 int qx, qy;
                 bool e;
 #define OAT_EDGE()  /* (qx, qy) is a neighbour of (x, y): |d| <= x + y < 2^15 (frames up to 16383 x 16383 take this path), the products fit 32 bits */ \
@@ -843,24 +851,24 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
                     const int dd = x * qy - qx * y;                                           \
                     s00 += dd; s10 += dd * (x + qx); s01 += dd * (y + qy);                    \
                 }
-                if (!(L & bit) && out_l) {                                                    // left
+                if (!(Lq & bit) && out_l) {                                                   // left
                     e = true;
-                    if (DL & bit) { qx = x - 1; qy = y + 1; } else if (Dn & bit) { qx = x; qy = y + 1; } else e = false;
+                    if (DLq & bit) { qx = x - 1; qy = y + 1; } else if (Dq & bit) { qx = x; qy = y + 1; } else e = false;
                     OAT_EDGE()
                 }
-                if (!(Dn & bit) && (!adj_dn || root_at(md, r + 1, x) == 0)) {                 // bottom
+                if (!(Dq & bit) && (!adj_dn || root_at(md, r + 1, x) == 0)) {                 // bottom
                     e = true;
-                    if (DR & bit) { qx = x + 1; qy = y + 1; } else if (Rr & bit) { qx = x + 1; qy = y; } else e = false;
+                    if (DRq & bit) { qx = x + 1; qy = y + 1; } else if (Rq & bit) { qx = x + 1; qy = y; } else e = false;
                     OAT_EDGE()
                 }
-                if (!(Rr & bit) && out_r) {                                                   // right
+                if (!(Rq & bit) && out_r) {                                                   // right
                     e = true;
-                    if (UR & bit) { qx = x + 1; qy = y - 1; } else if (U & bit) { qx = x; qy = y - 1; } else e = false;
+                    if (URq & bit) { qx = x + 1; qy = y - 1; } else if (Uq & bit) { qx = x; qy = y - 1; } else e = false;
                     OAT_EDGE()
                 }
-                if (!(U & bit) && (!adj_up || root_at(mu, r - 1, x) == 0)) {                  // top
+                if (!(Uq & bit) && (!adj_up || root_at(mu, r - 1, x) == 0)) {                 // top
                     e = true;
-                    if (UL & bit) { qx = x - 1; qy = y - 1; } else if (L & bit) { qx = x - 1; qy = y; } else e = false;
+                    if (ULq & bit) { qx = x - 1; qy = y - 1; } else if (Lq & bit) { qx = x - 1; qy = y; } else e = false;
                     OAT_EDGE()
                 }
 #undef OAT_EDGE
