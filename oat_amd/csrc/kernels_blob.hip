@@ -646,7 +646,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     __shared__ int rootnode[kLdsRoots];
     __shared__ unsigned long long acc[kLdsRoots * 3];
     __shared__ unsigned scan_d[16], scan_r[16];
-    __shared__ unsigned nroots_s;
+    __shared__ unsigned nroots_s, nfg_s;
+    __shared__ unsigned short fglist[kLdsRuns / 2 + 2];  // the foreground nodes, in any order (phase E walks these)
     __shared__ unsigned long long red[kLdsBlock / 64];
 
     const int s = first_stream + blockIdx.y;
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     const int *rowinfo = b.rowinfo + (size_t)s * g.H;
 
 #ifdef OATGPU_LDS_TIMING
-    long long tk[8]; int tn = 0;
+    long long tk[16]; int tn = 0;
 #define TK() tk[tn++] = wall_clock64()
 #else
 #define TK()
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         if (lane >= o) { di += vd; ri_ += vr; }
     }
     if (lane == 63) { scan_d[wave] = di; scan_r[wave] = ri_; }
-    if (t == 0) nroots_s = 0;
+    if (t == 0) { nroots_s = 0; nfg_s = 0; }
     __syncthreads();
     unsigned dbase = di - d, rbase = ri_ - rn, D = 0, R = 0;
     for (int i = 0; i < kLdsBlock / 64; ++i) {
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
                 rstart[node] = (unsigned short)(w * 64u + (unsigned)bit);
                 rrow[node] = (unsigned short)r;
                 par[node] = (int)node;
+                if ((node - rptr[r]) & 1u) fglist[atomicAdd(&nfg_s, 1u)] = (unsigned short)node;
                 node++;
             }
         }
@@ -792,14 +794,20 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     }
 
     TK();
-    // ---- E: Green sums over the edges facing OUTSIDE background: four threads per foreground run, thread q of the
-    // four taking bits 16q..16q+15 of every word (the per-bit loop is serial, and the top and bottom rows of a blob
+    // ---- E: Green sums over the edges facing OUTSIDE background: 4 to 16 threads per foreground run, each taking its
+    // share of the bits of every word (the per-bit loop is serial, and the top and bottom rows of a blob
     // are all border) ----
-    const u64 qbits = 0xffffull << (16 * (t & 3));
-    for (unsigned i0 = (unsigned)(t >> 2); i0 < R; i0 += kLdsBlock / 4) {
-        const unsigned i = 1 + i0;
-        const unsigned r = rrow[i], k = i - rptr[r];
-        if (!(k & 1u)) continue;
+    const unsigned NF = nfg_s;
+    // threads per run: 16, 8 or 4 -- as many as let all runs go in one pass (the per-bit loop below is serial and
+    // ~300 instructions long; a thread takes 64 / lpr bits of every word)
+    const int lpr_log = NF * 16u <= (unsigned)kLdsBlock ? 4 : (NF * 8u <= (unsigned)kLdsBlock ? 3 : 2);
+    const int lpr = 1 << lpr_log, nbits = 64 >> lpr_log, sub = t & (lpr - 1);
+    const int sh = nbits * sub;
+    const u64 qbits = ((nbits == 64 ? ~0ull : ((1ull << nbits) - 1ull))) << sh;
+    const unsigned qmask = (1u << nbits) - 1u;
+    for (unsigned i0 = (unsigned)(t >> lpr_log); i0 < NF; i0 += (unsigned)(kLdsBlock >> lpr_log)) {
+        const unsigned i = fglist[i0];
+        const unsigned r = rrow[i];
         const int y = rows[r];
         const int sx = rstart[i], ex = (int)rstart[i + 1] - 1;       // a foreground run is never the last of its row
         const bool adj_up = r > 0 && rows[r - 1] == y - 1, adj_dn = r + 1 < D && rows[r + 1] == y + 1;
@@ -817,23 +825,34 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         };
         long long s00 = 0, s10 = 0, s01 = 0;
         const size_t rc = (size_t)y * g.words, ru = rc - g.words, rd = rc + g.words;
+#ifdef OATGPU_LDS_TIMING
+        if (i0 == (unsigned)(t >> lpr_log)) { TK(); }
+#endif
         for (int w = sx >> 6; w <= (ex >> 6); ++w) {
             const int lo = max(sx - w * 64, 0), hi = min(ex - w * 64, 63);
             const u64 runbits = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull) & qbits;
-            if (!runbits) continue;                                  // nothing of the run in this thread's bits
-            const u64 cur = fin[rc + w];
+            // the threads of a run need the same nine words: thread 0 of them fetches the run's row, thread 1
+            // the row above, thread 2 the row below, and they pass them round (a quarter of the requests)
+            const int role = sub;
+            const size_t rbase = role == 0 ? rc : (role == 1 ? ru : rd);
             const bool hp = w > 0, hn = w + 1 < g.words;
-            const u64 U = fin[ru + w], Dn = fin[rd + w];
-            const u64 curP = hp ? fin[rc + w - 1] : 0ull, curN = hn ? fin[rc + w + 1] : 0ull;
-            const u64 upP = hp ? fin[ru + w - 1] : 0ull, upN = hn ? fin[ru + w + 1] : 0ull;
-            const u64 dnP = hp ? fin[rd + w - 1] : 0ull, dnN = hn ? fin[rd + w + 1] : 0ull;
+            u64 m0 = 0ull, mP = 0ull, mN = 0ull;
+            if (role < 3) {
+                m0 = fin[rbase + w];
+                mP = hp ? fin[rbase + w - 1] : 0ull;
+                mN = hn ? fin[rbase + w + 1] : 0ull;
+            }
+            const int quad = lane & ~(lpr - 1);
+            const u64 cur = __shfl(m0, quad), curP = __shfl(mP, quad), curN = __shfl(mN, quad);
+            const u64 U = __shfl(m0, quad + 1), upP = __shfl(mP, quad + 1), upN = __shfl(mN, quad + 1);
+            const u64 Dn = __shfl(m0, quad + 2), dnP = __shfl(mP, quad + 2), dnN = __shfl(mN, quad + 2);
+            if (!runbits) continue;                                  // nothing of the run in this thread's bits
             // this thread's 16 bits of the nine masks as 32-bit values: the per-bit loop below is what the kernel's
             // time goes into (one compute unit runs it), and on 64-bit masks it was twice as many instructions
-            const int sh = 16 * (t & 3);
             const u64 L64 = (cur << 1) | (curP >> 63), R64 = (cur >> 1) | (curN << 63);
             const u64 UL64 = (U << 1) | (upP >> 63), UR64 = (U >> 1) | (upN << 63);
             const u64 DL64 = (Dn << 1) | (dnP >> 63), DR64 = (Dn >> 1) | (dnN << 63);
-#define Q16(v) ((unsigned)((v) >> sh) & 0xffffu)
+#define Q16(v) ((unsigned)((v) >> sh) & qmask)
             const unsigned cq = Q16(cur & runbits), Lq = Q16(L64), Rq = Q16(R64), Uq = Q16(U), Dq = Q16(Dn);
             const unsigned ULq = Q16(UL64), URq = Q16(UR64), DLq = Q16(DL64), DRq = Q16(DR64);
 #undef Q16
@@ -881,6 +900,9 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
             atomicAdd(&acc[slot * 3 + 2], (unsigned long long)s01);
         }
     }
+#ifdef OATGPU_LDS_TIMING
+    TK();
+#endif
     __syncthreads();
 
     TK();
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         b.lds_ok[s] = 1u;
 #ifdef OATGPU_LDS_TIMING
         TK();
-        printf("lds D=%u R=%u NR=%u  A %lld B %lld C %lld D %lld E %lld F %lld (x10 ns)\n", D, R, NR, tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4], tk[6]-tk[5]);
+        printf("lds D=%u R=%u NR=%u NF=%u  A %lld B %lld C %lld D %lld  E: setup %lld own-loop %lld barrier-wait %lld  F %lld (x10 ns)\n", D, R, NR, NF, tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4], tk[6]-tk[5], tk[7]-tk[6], tk[8]-tk[7]);
 #endif
     }
 }
