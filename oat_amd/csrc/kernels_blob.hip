@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     __shared__ int rootnode[kLdsRoots];
     __shared__ unsigned long long acc[kLdsRoots * 3];
     __shared__ unsigned scan_d[16], scan_r[16];
-    __shared__ unsigned nroots_s, nfg_s;
+    __shared__ unsigned nroots_s;
     __shared__ unsigned short fglist[kLdsRuns / 2 + 2];  // the foreground nodes, in any order (phase E walks these)
     __shared__ unsigned long long red[kLdsBlock / 64];
 
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         if (lane >= o) { di += vd; ri_ += vr; }
     }
     if (lane == 63) { scan_d[wave] = di; scan_r[wave] = ri_; }
-    if (t == 0) { nroots_s = 0; nfg_s = 0; }
+    if (t == 0) nroots_s = 0;
     __syncthreads();
     unsigned dbase = di - d, rbase = ri_ - rn, D = 0, R = 0;
     for (int i = 0; i < kLdsBlock / 64; ++i) {
@@ -709,21 +709,41 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     __syncthreads();
 
     TK();
-    // ---- B: the run list ----
-    for (unsigned i = t; i < D * (unsigned)g.words; i += kLdsBlock) {
-        const unsigned r = i / (unsigned)g.words, w = i - r * (unsigned)g.words;
-        const size_t gi = (size_t)rows[r] * g.words + w;
-        u64 T = trans[gi];
-        if (T) {
-            unsigned node = rptr[r] + wpre[gi];
-            while (T) {
-                const int bit = lsb64(T);
-                T &= T - 1;
-                rstart[node] = (unsigned short)(w * 64u + (unsigned)bit);
-                rrow[node] = (unsigned short)r;
-                par[node] = (int)node;
-                if ((node - rptr[r]) & 1u) fglist[atomicAdd(&nfg_s, 1u)] = (unsigned short)node;
-                node++;
+    // ---- B: the run list ----  (four words per thread and trip: the loads of a trip are in flight together)
+    {
+        const unsigned total = D * (unsigned)g.words;
+        for (unsigned i0 = t; i0 < total; i0 += 4u * kLdsBlock) {
+            u64 T[4];
+            unsigned rr[4], pre[4];
+            size_t gi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = i0 + (unsigned)u * kLdsBlock, ic = min(i, total - 1u);   // (no branch round the load)
+                const unsigned r = ic / (unsigned)g.words, w = ic - r * (unsigned)g.words;
+                rr[u] = r;
+                gi[u] = (size_t)rows[r] * g.words + w;
+                T[u] = trans[gi[u]];
+                pre[u] = wpre[gi[u]];
+                if (i >= total) T[u] = 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                u64 Tu = T[u];
+                if (!Tu) continue;
+                const unsigned r = rr[u], w = (unsigned)(gi[u] - (size_t)rows[r] * g.words);
+                unsigned node = rptr[r] + pre[u];
+                while (Tu) {
+                    const int bit = lsb64(Tu);
+                    Tu &= Tu - 1;
+                    rstart[node] = (unsigned short)(w * 64u + (unsigned)bit);
+                    rrow[node] = (unsigned short)r;
+                    par[node] = (int)node;
+                    // (every row holds f foreground and f + 1 background runs: rows before r hold (rptr[r] - 1 - r) / 2
+                    // foreground runs -- the list index needs no counter)
+                    const unsigned kk = node - rptr[r];
+                    if (kk & 1u) fglist[((rptr[r] - 1u - r) >> 1) + (kk >> 1)] = (unsigned short)node;
+                    node++;
+                }
             }
         }
     }
@@ -797,7 +817,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     // ---- E: Green sums over the edges facing OUTSIDE background: 4 to 16 threads per foreground run, each taking its
     // share of the bits of every word (the per-bit loop is serial, and the top and bottom rows of a blob
     // are all border) ----
-    const unsigned NF = nfg_s;
+    const unsigned NF = (R - D) >> 1;
     // threads per run: 16, 8 or 4 -- as many as let all runs go in one pass (the per-bit loop below is serial and
     // ~300 instructions long; a thread takes 64 / lpr bits of every word)
     const int lpr_log = NF * 16u <= (unsigned)kLdsBlock ? 4 : (NF * 8u <= (unsigned)kLdsBlock ? 3 : 2);
