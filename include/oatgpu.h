@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 3     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes */
+#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color */
 
 enum {
     OATGPU_OK = 0,
@@ -207,6 +207,15 @@ int oatgpu_mog_filter(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *bgr_in,
 
 /* ColorConvert::filter with COLOR_BGR2HSV (ColorConvert.cpp:101-107). */
 int oatgpu_bgr2hsv(oatgpu_ctx *ctx, const uint8_t *bgr_in, uint8_t *hsv_out);
+
+/* ColorConvert::filter for any pair of colours (ColorConvert.cpp:101-107): from_color / to_color are
+ * oat::PixelColor values (BINARY 0, GREY 1, BGR 2, HSV 3; Color.h:29-34), the cvtColor code comes from
+ * oat::color_conv_table (Color.h:45-51): BGR -> GREY|BINARY (COLOR_BGR2GRAY -- the bridge `posidet thresh`
+ * and `posidet diff` need, SimpleThreshold.cpp:46, DifferenceDetector.cpp:44), GREY|BINARY -> BGR, BGR -> HSV,
+ * HSV -> BGR.  in: rows*cols*(1|3) bytes, out: rows*cols*(1|3) bytes, must not overlap unless equal in size.
+ * OATGPU_E_INVALID with the reference's texts for pairs with nothing to do (ColorConvert.cpp:79-85) or
+ * not possible (Color.h:88-95). */
+int oatgpu_cvt_color(oatgpu_ctx *ctx, int32_t from_color, int32_t to_color, const uint8_t *in, uint8_t *out);
 
 /* HSVDetector::detectPosition (HSVDetector.cpp:142-173): hsv_in rows*cols*3. */
 int oatgpu_detect_hsv(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *hsv_in,

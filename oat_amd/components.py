@@ -196,13 +196,26 @@ class Threshold(_Context):
         return out
 
 
+PIX_BINARY, PIX_GREY, PIX_BGR, PIX_HSV = 0, 1, 2, 3      # oat::PixelColor (Color.h:29-34)
+_COLOR_NAMES = {"BINARY": PIX_BINARY, "GREY": PIX_GREY, "BGR": PIX_BGR, "HSV": PIX_HSV}
+
+
 class ColorConvert(_Context):
-    """framefilt col -C HSV."""
+    """framefilt col -C COLOR (ColorConvert.cpp): `color` = the colour to convert to, as the reference's
+    --color option (default HSV, the bridge in front of `posidet hsv`); the source colour is what the
+    frame source carries (`from_color`, default BGR).  Pairs with nothing to do or not possible raise
+    with the reference's texts."""
+
+    def __init__(self, rows, cols, color="HSV", from_color="BGR", **kw):
+        super().__init__(rows, cols, **kw)
+        self.color_ = _COLOR_NAMES[color] if isinstance(color, str) else int(color)
+        self.from_ = _COLOR_NAMES[from_color] if isinstance(from_color, str) else int(from_color)
 
     def filter(self, frame):
-        f = _frame(frame, (self.rows, self.cols, 3))
-        out = np.empty_like(f)
-        self._chk(self.lib.oatgpu_bgr2hsv(self.ctx, ffi.u8(f), ffi.u8(out)))
+        shape_in = (self.rows, self.cols, 3) if self.from_ >= PIX_BGR else (self.rows, self.cols)
+        f = _frame(frame, shape_in)
+        out = np.empty((self.rows, self.cols, 3) if self.color_ >= PIX_BGR else (self.rows, self.cols), np.uint8)
+        self._chk(self.lib.oatgpu_cvt_color(self.ctx, self.from_, self.color_, ffi.u8(f), ffi.u8(out)))
         return out
 
 

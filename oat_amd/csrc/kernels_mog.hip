@@ -630,6 +630,102 @@ void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st
     hipLaunchKernelGGL(k_bgr2hsv, dim3(blocks), dim3(256), 0, st, bgr, hsv, npx);
 }
 
+// ---- the other entries of oat::color_conv_table (Color.h:45-51) behind ColorConvert::filter (ColorConvert.cpp:101-107) ----
+// Four pixels a thread, every access a dword (4 px x 3 B = three dwords; 4 grey px = one); the last npx % 4 pixels
+// are done byte-wise by the thread behind the last full group.
+
+// COLOR_BGR2GRAY on 8U: RGB2Gray<uchar>'s table sums = (1868 B + 9617 G + 4899 R + 2^13) >> 14
+__device__ __forceinline__ unsigned grey_of(unsigned b, unsigned g, unsigned r)
+{
+    return (1868u * b + 9617u * g + 4899u * r + (1u << 13)) >> 14;
+}
+
+// COLOR_HSV2BGR on 8U, OpenCV 3.1.0: HSV2RGB_b over HSV2RGB_f(hrange 180) -- fp32, every operation rounded on its own
+// (-ffp-contract=off), cvRound (nearest even) + saturation on the way out.  h <= 255 -> h * (6/180) < 8.5: the
+// reference's "do h -= 6 while (h >= 6)" runs once at most and the sector is always one of 0..5.
+__device__ __forceinline__ void hsv2bgr_px(unsigned hh, unsigned ss, unsigned vv, unsigned &b, unsigned &g, unsigned &r)
+{
+    float h = (float)hh;
+    const float s = (float)ss * (1.f / 255.f), v = (float)vv * (1.f / 255.f);
+    float fb, fg, fr;
+    if (s == 0.f) fb = fg = fr = v;
+    else {
+        h *= 6.f / 180.f;
+        if (h >= 6.f) h -= 6.f;
+        const int sector = (int)floorf(h);
+        h -= (float)sector;
+        const float t0 = v, t1 = v * (1.f - s), t2 = v * (1.f - s * h), t3 = v * (1.f - s * (1.f - h));
+        switch (sector) {                       // sector_data[][3] of HSV2RGB_f, (b, g, r)
+        case 0:  fb = t1; fg = t3; fr = t0; break;
+        case 1:  fb = t1; fg = t0; fr = t2; break;
+        case 2:  fb = t3; fg = t0; fr = t1; break;
+        case 3:  fb = t0; fg = t2; fr = t1; break;
+        case 4:  fb = t0; fg = t1; fr = t3; break;
+        default: fb = t2; fg = t1; fr = t0; break;
+        }
+    }
+    b = (unsigned)min(max(__float2int_rn(fb * 255.f), 0), 255);
+    g = (unsigned)min(max(__float2int_rn(fg * 255.f), 0), 255);
+    r = (unsigned)min(max(__float2int_rn(fr * 255.f), 0), 255);
+}
+
+template <int kCode>   // 0: BGR -> GREY, 1: GREY -> BGR, 2: HSV -> BGR
+__global__ __launch_bounds__(256) void k_cvt_color(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t npx)
+{
+    const size_t groups = npx >> 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < groups) {
+        if (kCode == 1) {
+            const unsigned q = ((const unsigned *)in)[t];
+            const unsigned p0 = q & 255u, p1 = (q >> 8) & 255u, p2 = (q >> 16) & 255u, p3 = q >> 24;
+            unsigned *o = (unsigned *)out + 3 * t;
+            o[0] = p0 * 0x010101u | p1 << 24;
+            o[1] = p1 * 0x0101u | p2 * 0x01010000u;
+            o[2] = p2 | p3 * 0x01010100u;
+        } else {
+            const unsigned *w = (const unsigned *)in + 3 * t;
+            const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+            // channel c of pixel k is byte 3k + c of the twelve
+            const unsigned a0 = w0 & 255u, a1 = (w0 >> 8) & 255u, a2 = (w0 >> 16) & 255u;
+            const unsigned b0 = w0 >> 24, b1 = w1 & 255u, b2 = (w1 >> 8) & 255u;
+            const unsigned c0 = (w1 >> 16) & 255u, c1 = w1 >> 24, c2 = w2 & 255u;
+            const unsigned d0 = (w2 >> 8) & 255u, d1 = (w2 >> 16) & 255u, d2 = w2 >> 24;
+            if (kCode == 0) {
+                ((unsigned *)out)[t] = grey_of(a0, a1, a2) | grey_of(b0, b1, b2) << 8 | grey_of(c0, c1, c2) << 16 |
+                                       grey_of(d0, d1, d2) << 24;
+            } else {
+                unsigned pb[4], pg[4], pr[4];
+                hsv2bgr_px(a0, a1, a2, pb[0], pg[0], pr[0]);
+                hsv2bgr_px(b0, b1, b2, pb[1], pg[1], pr[1]);
+                hsv2bgr_px(c0, c1, c2, pb[2], pg[2], pr[2]);
+                hsv2bgr_px(d0, d1, d2, pb[3], pg[3], pr[3]);
+                unsigned *o = (unsigned *)out + 3 * t;
+                o[0] = pb[0] | pg[0] << 8 | pr[0] << 16 | pb[1] << 24;
+                o[1] = pg[1] | pr[1] << 8 | pb[2] << 16 | pg[2] << 24;
+                o[2] = pr[2] | pb[3] << 8 | pg[3] << 16 | pr[3] << 24;
+            }
+        }
+    } else if (t == groups) {
+        for (size_t i = groups << 2; i < npx; ++i) {
+            if (kCode == 0) out[i] = (uint8_t)grey_of(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+            else if (kCode == 1) out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = in[i];
+            else {
+                unsigned b, g, r;
+                hsv2bgr_px(in[3 * i], in[3 * i + 1], in[3 * i + 2], b, g, r);
+                out[3 * i] = (uint8_t)b; out[3 * i + 1] = (uint8_t)g; out[3 * i + 2] = (uint8_t)r;
+            }
+        }
+    }
+}
+
+void launch_cvt_color(int code, const uint8_t *in, uint8_t *out, size_t npx, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)(((npx >> 2) + 1 + 255) / 256);
+    if (code == 0) hipLaunchKernelGGL(k_cvt_color<0>, dim3(blocks), dim3(256), 0, st, in, out, npx);
+    else if (code == 1) hipLaunchKernelGGL(k_cvt_color<1>, dim3(blocks), dim3(256), 0, st, in, out, npx);
+    else hipLaunchKernelGGL(k_cvt_color<2>, dim3(blocks), dim3(256), 0, st, in, out, npx);
+}
+
 // one wave = one mask word (64 pixels of one row)
 __global__ __launch_bounds__(256) void k_inrange_bits(Geom g, const uint8_t *frame, int channels,
                                                       RangeParams rp, u64 *bits)

@@ -764,6 +764,35 @@ extern "C" int oatgpu_bgr2hsv(oatgpu_ctx *c, const uint8_t *bgr_in, uint8_t *hsv
     return OATGPU_OK;
 }
 
+// ColorConvert::filter for any pair of oat::PixelColor values: oat::color_conv_table (Color.h:45-51) picks the
+// cvtColor code, color_conv_code (Color.h:88-95) refuses the impossible pairs and ColorConvert::connectToNode
+// (ColorConvert.cpp:79-85) the ones with nothing to do -- same texts here.
+extern "C" int oatgpu_cvt_color(oatgpu_ctx *c, int32_t from_color, int32_t to_color, const uint8_t *in, uint8_t *out)
+{
+    if (!c || !in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    static const char *const names[4] = {"BINARY", "GREY", "BGR", "HSV"};
+    if (from_color < 0 || from_color > 3 || to_color < 0 || to_color > 3) return fail(c, OATGPU_E_INVALID, "Invalid color.");
+    //                       to: BINARY GREY BGR HSV        -1 nothing to do, -2 not possible, 3 = BGR -> HSV
+    static const int table[4][4] = {{-1, -1, 1, -2},      // from BINARY
+                                    {-1, -1, 1, -2},      // from GREY
+                                    {0, 0, -1, 3},        // from BGR
+                                    {-2, -2, 2, -1}};     // from HSV
+    const int code = table[from_color][to_color];
+    if (code == -2) return fail(c, OATGPU_E_INVALID, "Requested color conversion is not possible.");
+    if (code == -1)
+        return fail(c, OATGPU_E_INVALID, "Nothing to be done for %s to %s conversion.", names[from_color], names[to_color]);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t npx = (size_t)c->g.H * c->g.W;
+    const size_t nin = npx * (from_color >= 2 ? 3 : 1), nout = npx * (to_color >= 2 ? 3 : 1);
+    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nin, hipMemcpyHostToDevice, c->stream));
+    if (code == 3) launch_bgr2hsv(c->aux_a, c->aux_b, npx, c->stream);
+    else launch_cvt_color(code, c->aux_a, c->aux_b, npx, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
 // contourMoments' epilogue (imgproc/moments.cpp) + siftContours' centroid
 // (DetectorFunc.cpp:54-62) on the exact integer sums.
 static void to_position(const ResultRec &r, oatgpu_position *o)

@@ -102,6 +102,8 @@ void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);
 void launch_density_probe(const uint8_t *nmodes, size_t total, unsigned *out, hipStream_t st);   // out = {live modes, samples}
 void launch_nop(hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
 void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
+// code 0: BGR -> GREY, 1: GREY -> BGR, 2: HSV -> BGR (Color.h:45-51); in/out 4-byte aligned
+void launch_cvt_color(int code, const uint8_t *in, uint8_t *out, size_t npx, hipStream_t st);
 // 3-channel (HSV) or 1-channel (grey) inRange of ONE frame into a bit mask.
 void launch_inrange_bits(const Geom &g, const uint8_t *frame, int channels, const RangeParams &rp,
                          u64 *bits, hipStream_t st);

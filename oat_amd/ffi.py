@@ -52,7 +52,7 @@ class Traffic(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 3          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 4          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -83,6 +83,7 @@ SIGNATURES = {
     "oatgpu_mog_apply": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_mog_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
+    "oatgpu_cvt_color": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p, _u8p]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_diff": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),

@@ -39,6 +39,16 @@ inline const char *color_str(PixelColor c)
     throw std::runtime_error("Invalid color.");
 }
 
+// Color.h:65-77
+inline PixelColor str_color(const std::string &s)
+{
+    if (s == "BINARY") return PIX_BINARY;
+    if (s == "GREY") return PIX_GREY;
+    if (s == "BGR") return PIX_BGR;
+    if (s == "HSV") return PIX_HSV;
+    throw std::runtime_error("Invalid color.");
+}
+
 // lib/datatypes/Sample.h:35-123
 class Sample {
 public:

@@ -1,6 +1,6 @@
 // oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]
 //   TYPE  mog   MI355X replacement of `oat framefilt mog`  (src/framefilter/BackgroundSubtractorMOG.cpp)
-//         col   MI355X replacement of `oat framefilt col`  (src/framefilter/ColorConvert.cpp), BGR->HSV only
+//         col   MI355X replacement of `oat framefilt col`  (src/framefilter/ColorConvert.cpp): every pair of oat::color_conv_table
 //         bsub  MI355X replacement of `oat framefilt bsub` (src/framefilter/BackgroundSubtractor.cpp)
 //         thresh MI355X replacement of `oat framefilt thresh` (src/framefilter/Threshold.cpp)
 // Drop-in: same positional arguments, same option names (src/framefilter/main.cpp:91-296).
@@ -24,10 +24,13 @@ public:
 protected:
     void configure_for(const FrameParams &p) override
     {
-        if (p.color != PIX_BGR) throw std::runtime_error("framefilt mog (hip) needs BGR frames");
+        // cv::BackgroundSubtractorMOG2::apply takes any 8U frame of one or three channels and the reference
+        // passes on whatever colour its source carries (FrameFilter.cpp:37-57): GREY frames of a
+        // `framefilt col -C GREY` or a mono camera run the one-channel model
         oatgpu_config cfg;
         oatgpu_default_config(&cfg);
         cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols; cfg.n_streams = 1;
+        cfg.channels = color_bytes(p.color);
         gpu_.create(cfg);
         if (!model_file_.empty() && access(model_file_.c_str(), R_OK) == 0)
             gpu_.check(oatgpu_mog_load(gpu_.ctx, 0, model_file_.c_str()));
@@ -48,15 +51,20 @@ protected:
 class ColorConvert : public FrameFilter {
 public:
     using FrameFilter::FrameFilter;
-    PixelColor color_{PIX_HSV};
+    PixelColor color_{PIX_BGR};     // ColorConvert.h: color_ {PIX_BGR}; --color is required (ColorConvert.cpp:58-63)
     int gpu_index_{0};
 
 protected:
+    // oat::color_conv_code (Color.h:88-95) + ColorConvert::connectToNode (ColorConvert.cpp:76-85): the table
+    // lives behind oatgpu_cvt_color; here only its two refusals, raised at connect time as the reference does
     PixelColor sink_color(PixelColor in) const override
     {
-        if (in != PIX_BGR || color_ != PIX_HSV)   // color_conv_table, Color.h:46-51: only BGR->HSV is on the hot path
-            throw std::runtime_error("framefilt col (hip) converts BGR to HSV only");
-        return PIX_HSV;
+        static const int table[4][4] = {{-1, -1, 0, -2}, {-1, -1, 0, -2}, {0, 0, -1, 0}, {-2, -2, 0, -1}};
+        const int code = table[in][color_];
+        if (code == -2) throw std::runtime_error("Requested color conversion is not possible.");
+        if (code == -1)
+            throw std::runtime_error(std::string("Nothing to be done for ") + color_str(in) + " to " + color_str(color_) + " conversion.");
+        return color_;
     }
     void configure_for(const FrameParams &p) override
     {
@@ -64,20 +72,24 @@ protected:
         oatgpu_default_config(&cfg);
         cfg.device = gpu_index_; cfg.rows = (int)p.rows; cfg.cols = (int)p.cols;
         gpu_.create(cfg);
+        from_ = p.color;
     }
-    // ColorConvert.cpp:101-107
+    // ColorConvert.cpp:101-107.  Not in place: the two sides may differ in bytes per pixel.
     void filter(Frame &frame) override
     {
-        gpu_.check(oatgpu_bgr2hsv(gpu_.ctx, frame.data(), frame.data()));
-        frame.set_color(PIX_HSV);
+        Frame out(frame.rows(), frame.cols(), color_);
+        gpu_.check(oatgpu_cvt_color(gpu_.ctx, (int)from_, (int)color_, frame.data(), out.data()));
+        out.sample() = frame.sample();
+        frame = std::move(out);
     }
     bool filter_from_shm(const Frame &in, Frame &out) override
     {
-        gpu_.check(oatgpu_bgr2hsv(gpu_.ctx, in.data(), out.data()));
-        out.set_color(PIX_HSV);
+        gpu_.check(oatgpu_cvt_color(gpu_.ctx, (int)in.color(), (int)color_, in.data(), out.data()));
+        out.set_color(color_);
         return true;
     }
     GpuCtx gpu_;
+    PixelColor from_{PIX_BGR};
 };
 
 class BackgroundSubtractor : public FrameFilter {
@@ -181,12 +193,12 @@ protected:
 static void usage()
 {
     std::cout << "Usage: oat-framefilt-hip TYPE SOURCE SINK [CONFIGURATION]\n"
-                 "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: BGR -> HSV colour conversion on an MI355X\n"
+                 "TYPE\n  mog: MOG2 background segmentation on an MI355X\n  col: colour conversion (BGR -> HSV | GREY, GREY -> BGR, HSV -> BGR) on an MI355X\n"
                  "  bsub | thresh | mask: the other per-pixel filters of oat-framefilt\n"
                  "all:  --gpu-index N           HIP device ordinal (default 0)\n"
                  "mog:  -a, --adaptation-coeff  0..1, default 0 (no adaptation)\n"
                  "      --model-file FILE    resume the background model from FILE if it exists; checkpoint it there on exit\n"
-                 "col:  -C, --color             HSV\n"
+                 "col:  -C, --color             colour to convert to: GREY | BGR | HSV (required)\n"
                  "bsub: -a, --adaptation-coeff  0..1, default 0 (static background = first frame)\n"
                  "      -f, --background FILE   PGM/PPM background image instead of the first frame\n"
                  "mask: -f, --mask FILE         PGM/PPM: pixels where it is 0 are set to 0\n"
@@ -220,7 +232,8 @@ int main(int argc, char **argv)
             comp = std::move(f);
         } else if (type == "col") {
             auto f = std::make_unique<ColorConvert>(o.positional[1], o.positional[2]);
-            if (o.has("color") && o.kv["color"] != "HSV") throw std::runtime_error("only -C HSV is supported");
+            if (!o.has("color")) throw std::runtime_error("Required configuration value 'color' was not specified.");   // TOMLSanitize.h:199-200 via ColorConvert.cpp:59-60
+            f->color_ = str_color(o.kv["color"]);                                 // Color.h:65-77
             f->gpu_index_ = gpu_index;
             comp = std::move(f);
         } else if (type == "bsub") {

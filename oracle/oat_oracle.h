@@ -86,6 +86,17 @@ void oat_mog2_get_state(const oat_mog2 *m, float *weight, float *variance, float
  * OpenCV RGB2HSV_b, hrange 180, hsv_shift 12). */
 void oat_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npixels);
 
+/* The other entries of oat::color_conv_table (Color.h:45-51), which `framefilt col`
+ * reaches through the same cv::cvtColor call (ColorConvert.cpp:104): BGR -> GREY
+ * (COLOR_BGR2GRAY, what `posidet thresh` / `diff` need in front of them,
+ * SimpleThreshold.cpp:46, DifferenceDetector.cpp:44), GREY -> BGR, HSV -> BGR. */
+void oat_bgr2grey(const uint8_t *bgr, uint8_t *grey, size_t npixels);
+void oat_grey2bgr(const uint8_t *grey, uint8_t *bgr, size_t npixels);
+void oat_hsv2bgr(const uint8_t *hsv, uint8_t *bgr, size_t npixels);
+/* table lookup + conversion; from/to = oat::PixelColor.  Returns bytes per output
+ * pixel, -1 "nothing to be done", -2 "not possible". */
+int oat_cvt_color(int from, int to, const uint8_t *src, uint8_t *dst, size_t npixels);
+
 /* cv::inRange on 3-channel / 1-channel 8U data with integer scalar bounds
  * (HSVDetector.cpp:146-149, SimpleThreshold.cpp:171-174).  Bounds inclusive;
  * lo > hi or lo > 255 -> empty; hi saturates to 255. */
@@ -155,9 +166,6 @@ typedef struct oat_bsub oat_bsub;
 oat_bsub *oat_bsub_create(int rows, int cols, int channels, double alpha);
 void oat_bsub_destroy(oat_bsub *b);
 void oat_bsub_filter(oat_bsub *b, uint8_t *frame);
-
-/* cv::cvtColor(.., COLOR_BGR2GRAY) for 8U (RGB2Gray<uchar>: (1868 B + 9617 G + 4899 R + 8192) >> 14). */
-void oat_bgr2grey(const uint8_t *bgr, uint8_t *grey, size_t npixels);
 
 /* framefilt thresh, Threshold.cpp:67-81: grey conversion (BGR frames) -> inRange(i_min, i_max) ->
  * frame.setTo(0, thresh == 0).  channels 3 (BGR) or 1 (GREY); in place. */

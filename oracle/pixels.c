@@ -4,6 +4,10 @@
  *
  *   oat_bgr2hsv     ColorConvert.cpp:101-107  cv::cvtColor(.., COLOR_BGR2HSV)
  *                   = OpenCV 3.1.0 imgproc/color.cpp RGB2HSV_b (hrange 180)
+ *   oat_bgr2grey    ColorConvert.cpp:101-107 with Color.h:49 (BGR -> GREY / BINARY)
+ *                   = RGB2Gray<uchar>, 14-bit fixed-point luma table
+ *   oat_grey2bgr    Color.h:47-48 (GREY / BINARY -> BGR) = Gray2RGB<uchar>
+ *   oat_hsv2bgr     Color.h:50 (HSV -> BGR) = HSV2RGB_b over HSV2RGB_f, hrange 180
  *   oat_inrange3/1  HSVDetector.cpp:146-149 / SimpleThreshold.cpp:171-174
  *                   = core/arithm.cpp cv::inRange with scalar bounds on 8U
  *   oat_erode_rect  HSVDetector.cpp:152-153 (+ :253-262 structuring element)
@@ -68,6 +72,103 @@ void oat_bgr2hsv(const uint8_t *src, uint8_t *dst, size_t n)
         dst[1] = (uint8_t)s;
         dst[2] = (uint8_t)v;
     }
+}
+
+/* ---------------------------------------------- the other cvtColor codes ---- */
+
+/* cv::cvtColor(.., COLOR_BGR2GRAY) on CV_8UC3, OpenCV 3.1.0 imgproc/color.cpp
+ * RGB2Gray<uchar>: a 3 x 256 table of the running sums b += B2Y, g += G2Y,
+ * r += R2Y with R2Y 4899, G2Y 9617, B2Y 1868 (yuv_shift 14), the rounding
+ * half (1 << 13) folded into the red column; grey = (tab[b] + tab[g+256] +
+ * tab[r+512]) >> 14.  (The IPP route of 3.1.0's cvtColor serves CV_32F only.) */
+void oat_bgr2grey(const uint8_t *src, uint8_t *dst, size_t n)
+{
+    enum { yuv_shift = 14, R2Y = 4899, G2Y = 9617, B2Y = 1868 };
+    int tab[768];
+    int b = 0, g = 0, r = 1 << (yuv_shift - 1);
+    for (int i = 0; i < 256; i++, b += B2Y, g += G2Y, r += R2Y) {
+        tab[i] = b;
+        tab[i + 256] = g;
+        tab[i + 512] = r;
+    }
+    for (size_t i = 0; i < n; i++, src += 3)
+        dst[i] = (uint8_t)((tab[src[0]] + tab[src[1] + 256] + tab[src[2] + 512]) >> yuv_shift);
+}
+
+/* cv::cvtColor(.., COLOR_GRAY2BGR): Gray2RGB<uchar>, every channel = grey. */
+void oat_grey2bgr(const uint8_t *src, uint8_t *dst, size_t n)
+{
+    for (size_t i = 0; i < n; i++, dst += 3) dst[0] = dst[1] = dst[2] = src[i];
+}
+
+/* cv::cvtColor(.., COLOR_HSV2BGR) on CV_8UC3, OpenCV 3.1.0: HSV2RGB_b turns a
+ * pixel into floats (h, s * (1.f/255.f), v * (1.f/255.f)), runs HSV2RGB_f with
+ * hscale = 6.f / 180 and stores saturate_cast<uchar>(c * 255.f) (= cvRound,
+ * round half to even).  float arithmetic throughout, every operation rounded
+ * on its own (-ffp-contract=off).  (OpenCV >= 3.4 replaced this by a fixed-point
+ * routine whose results differ by one level here and there; Oat pins 3.1.0.) */
+void oat_hsv2bgr(const uint8_t *src, uint8_t *dst, size_t n)
+{
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    const float hscale = 6.f / 180.f;
+    for (size_t i = 0; i < n; i++, src += 3, dst += 3) {
+        float h = src[0], s = src[1] * (1.f / 255.f), v = src[2] * (1.f / 255.f);
+        float b, g, r;
+        if (s == 0)
+            b = g = r = v;
+        else {
+            float tab[4];
+            int sector;
+            h *= hscale;
+            if (h < 0)
+                do h += 6; while (h < 0);
+            else if (h >= 6)
+                do h -= 6; while (h >= 6);
+            sector = (int)floorf(h);
+            h -= sector;
+            if ((unsigned)sector >= 6u) {
+                sector = 0;
+                h = 0.f;
+            }
+            tab[0] = v;
+            tab[1] = v * (1.f - s);
+            tab[2] = v * (1.f - s * h);
+            tab[3] = v * (1.f - s * (1.f - h));
+            b = tab[sector_data[sector][0]];
+            g = tab[sector_data[sector][1]];
+            r = tab[sector_data[sector][2]];
+        }
+        const float c[3] = {b * 255.f, g * 255.f, r * 255.f};
+        for (int k = 0; k < 3; k++) {
+            long q = lrintf(c[k]);           /* cvRound: nearest, ties to even */
+            dst[k] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+        }
+    }
+}
+
+/* oat::color_conv_table (Color.h:45-51) behind ColorConvert::filter
+ * (ColorConvert.cpp:101-107).  Colours are oat::PixelColor values (BINARY 0,
+ * GREY 1, BGR 2, HSV 3).  Returns bytes per output pixel, -1 = "nothing to be
+ * done" (ColorConvert.cpp:79-85 throws), -2 = "not possible" (Color.h:92-93). */
+int oat_cvt_color(int from, int to, const uint8_t *src, uint8_t *dst, size_t n)
+{
+    if (from < 0 || from > 3 || to < 0 || to > 3) return -2;
+    if (from <= 1) {
+        if (to <= 1) return -1;
+        if (to == 3) return -2;
+        oat_grey2bgr(src, dst, n);
+        return 3;
+    }
+    if (from == 2) {
+        if (to == 2) return -1;
+        if (to == 3) { oat_bgr2hsv(src, dst, n); return 3; }
+        oat_bgr2grey(src, dst, n);
+        return 1;
+    }
+    if (to == 3) return -1;
+    if (to <= 1) return -2;
+    oat_hsv2bgr(src, dst, n);
+    return 3;
 }
 
 /* ------------------------------------------------------------- inRange ---- */
@@ -237,12 +338,6 @@ void oat_bsub_filter(oat_bsub *b, uint8_t *frame)
     }
     for (size_t i = 0; i < n; i++)                      /* frame - background, saturating */
         frame[i] = frame[i] > b->bg[i] ? (uint8_t)(frame[i] - b->bg[i]) : 0;
-}
-
-void oat_bgr2grey(const uint8_t *bgr, uint8_t *grey, size_t n)
-{
-    for (size_t i = 0; i < n; i++, bgr += 3)
-        grey[i] = (uint8_t)((1868 * bgr[0] + 9617 * bgr[1] + 4899 * bgr[2] + (1 << 13)) >> 14);
 }
 
 void oat_thresh_filter(uint8_t *frame, size_t n, int channels, int i_min, int i_max)

@@ -185,6 +185,34 @@ def kalman_trace(samples, dt=0.02, timeout=0.0, sigma_accel=5.0, sigma_noise=0.0
     return out
 
 
+def bgr2grey_restated(bgr):
+    """COLOR_BGR2GRAY on 8U written out as the closed form of RGB2Gray<uchar>'s table sums
+    (python ints, no table): (1868 B + 9617 G + 4899 R + 2^13) >> 14."""
+    bgr = np.asarray(bgr, np.int64)
+    return ((1868 * bgr[..., 0] + 9617 * bgr[..., 1] + 4899 * bgr[..., 2] + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def hsv2bgr_restated(hsv):
+    """COLOR_HSV2BGR on 8U as OpenCV 3.1.0 does it (HSV2RGB_b over HSV2RGB_f, hrange 180), vectorised in
+    numpy float32 -- every operation rounds to float32 on its own, np.rint = round half to even (cvRound)."""
+    f = np.float32
+    hsv = np.asarray(hsv, np.uint8)
+    h = hsv[..., 0].astype(f)
+    s = hsv[..., 1].astype(f) * f(f(1) / f(255))
+    v = hsv[..., 2].astype(f) * f(f(1) / f(255))
+    h = h * f(f(6) / f(180))
+    h = np.where(h >= f(6), h - f(6), h).astype(f)
+    sector = np.floor(h).astype(np.int64)
+    h = (h - sector.astype(f)).astype(f)
+    one = f(1)
+    tab = np.stack([v, v * (one - s), v * (one - s * h), v * (one - s * (one - h))], -1).astype(f)
+    sector_data = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    idx = sector_data[sector]                                   # (..., 3) -> which tab entry is b, g, r
+    bgr = np.take_along_axis(tab, idx, -1)
+    bgr = np.where((s == 0)[..., None], v[..., None], bgr).astype(f)
+    return np.clip(np.rint(bgr * f(255)), 0, 255).astype(np.uint8)
+
+
 def main():
     rng = np.random.default_rng(20260929)
 
@@ -196,6 +224,22 @@ def main():
                     [0, 0, 0], [46, 242, 200], [105, 3, 201], [0, 0, 255], [150, 255, 255],
                     [90, 255, 255]])
     json.dump(hsv, open(os.path.join(HERE, "hsv_kat.json"), "w"), indent=1)
+
+    # ---- the other conversions of `framefilt col` (Color.h:45-51): known answers from the restatements above ----
+    # grey: the well-known luma of the primaries (blue 29, green 150, red 76), yellow 226, white 255
+    # hsv -> bgr: the primaries/secondaries come back exactly; h = 180..255 wraps round (h * 6/180 >= 6)
+    colours = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 255, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128],
+               [10, 200, 100], [201, 200, 199], [255, 64, 0], [1, 1, 1], [254, 255, 253]]
+    rng_cvt = np.random.default_rng(20260930)      # its own generator: the vectors below keep theirs
+    colours += rng_cvt.integers(0, 256, (52, 3)).tolist()
+    hsvs = [[0, 255, 255], [60, 255, 255], [120, 255, 255], [30, 255, 255], [0, 0, 128], [0, 0, 0], [46, 242, 200],
+            [105, 3, 201], [179, 255, 255], [180, 255, 255], [255, 255, 255], [90, 128, 77], [15, 1, 254]]
+    hsvs += rng_cvt.integers(0, 256, (51, 3)).tolist()
+    cvt = dict(bgr=colours, grey=bgr2grey_restated(colours).tolist(),
+               hsv=hsvs, bgr_of_hsv=hsv2bgr_restated(hsvs).tolist())
+    assert cvt["grey"][:5] == [29, 150, 76, 226, 255]
+    assert cvt["bgr_of_hsv"][:4] == [[0, 0, 255], [0, 255, 0], [255, 0, 0], [0, 255, 255]]
+    json.dump(cvt, open(os.path.join(HERE, "cvt_color_kat.json"), "w"))
 
     # ---- contour known answers (hand derivations in comments) ----
     def blank(h, w): return [[0] * w for _ in range(h)]

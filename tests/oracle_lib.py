@@ -92,6 +92,10 @@ def _load():
     lib.oat_bsub_destroy.argtypes = [C.c_void_p]
     lib.oat_bsub_filter.argtypes = [C.c_void_p, u8p]
     lib.oat_bgr2grey.argtypes = [u8p, u8p, C.c_size_t]
+    lib.oat_grey2bgr.argtypes = [u8p, u8p, C.c_size_t]
+    lib.oat_hsv2bgr.argtypes = [u8p, u8p, C.c_size_t]
+    lib.oat_cvt_color.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_size_t]
+    lib.oat_cvt_color.restype = C.c_int
     lib.oat_thresh_filter.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
     lib.oat_blur_box.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
     lib.oat_diff_create.restype = C.c_void_p
@@ -315,6 +319,37 @@ def bgr2grey(bgr):
     out = np.empty(bgr.shape[:-1], np.uint8)
     lib.oat_bgr2grey(_p(bgr), _p(out), out.size)
     return out
+
+
+def grey2bgr(grey):
+    grey = _c(grey)
+    out = np.empty(grey.shape + (3,), np.uint8)
+    lib.oat_grey2bgr(_p(grey), _p(out), grey.size)
+    return out
+
+
+def hsv2bgr(hsv):
+    hsv = _c(hsv)
+    out = np.empty_like(hsv)
+    lib.oat_hsv2bgr(_p(hsv), _p(out), hsv.size // 3)
+    return out
+
+
+BINARY, GREY, BGR, HSV = 0, 1, 2, 3            # oat::PixelColor (Color.h:29-34)
+
+
+def cvt_color(frame, src, dst):
+    """ColorConvert::filter through oat::color_conv_table; returns (code, frame): code = bytes per
+    output pixel, -1 nothing to be done, -2 not possible (frame None then)."""
+    f = _c(frame)
+    ch_in = 3 if src >= 2 else 1
+    npx = f.size // ch_in
+    out = np.empty(npx * 3, np.uint8)
+    rc = lib.oat_cvt_color(int(src), int(dst), _p(f), _p(out), npx)
+    if rc < 0:
+        return rc, None
+    shape = f.shape[:-1] if ch_in == 3 else f.shape
+    return rc, (out[:npx * 3].reshape(shape + (3,)) if rc == 3 else out[:npx].reshape(shape))
 
 
 def thresh_filter(frame, i_min, i_max):

@@ -65,6 +65,80 @@ def test_bgr2hsv_known_answers(A, golden_dir):
     assert got[0, :len(g["bgr"])].tolist() == g["hsv"]
 
 
+def test_cvt_color_exhaustive_256cubed(A):
+    """`framefilt col` beyond HSV (oat::color_conv_table, Color.h:45-51): BGR -> GREY and HSV -> BGR over all
+    16.7M inputs (hues beyond 179 included), GREY -> BGR over a full frame."""
+    n = 4096
+    idx = np.arange(n * n, dtype=np.uint32)
+    px = np.stack([(idx & 255), (idx >> 8) & 255, (idx >> 16) & 255], -1).astype(np.uint8).reshape(n, n, 3)
+    got = A.ColorConvert(n, n, color="GREY").filter(px)
+    assert got.shape == (n, n) and (got == O.bgr2grey(px)).all()
+    got = A.ColorConvert(n, n, color="BINARY").filter(px)          # BGR -> BINARY is COLOR_BGR2GRAY as well
+    assert (got == O.bgr2grey(px)).all()
+    got = A.ColorConvert(n, n, color="BGR", from_color="HSV").filter(px)
+    assert (got == O.hsv2bgr(px)).all()
+    grey = (idx * 2654435761 >> 13).astype(np.uint8).reshape(n, n)
+    got = A.ColorConvert(n, n, color="BGR", from_color="GREY").filter(grey)
+    assert got.shape == (n, n, 3) and (got == grey[..., None]).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 3), (3, 5), (7, 9), (37, 101), (2, 2)])
+def test_cvt_color_ragged_sizes_and_known_answers(A, golden_dir, shape):
+    """Pixel counts that are not a multiple of the kernel's four-pixel groups; the golden known answers."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 131 + cols)
+    bgr = rng.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    g = json.load(open(os.path.join(golden_dir, "cvt_color_kat.json")))
+    k = min(rows * cols, len(g["bgr"]))
+    bgr.reshape(-1, 3)[:k] = g["bgr"][:k]
+    hsv = rng.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    hsv.reshape(-1, 3)[:k] = g["hsv"][:k]
+    got = A.ColorConvert(rows, cols, color="GREY").filter(bgr)
+    assert (got == O.bgr2grey(bgr)).all() and got.reshape(-1)[:k].tolist() == g["grey"][:k]
+    got = A.ColorConvert(rows, cols, color="BGR", from_color="HSV").filter(hsv)
+    assert (got == O.hsv2bgr(hsv)).all() and got.reshape(-1, 3)[:k].tolist() == g["bgr_of_hsv"][:k]
+    grey = bgr[..., 1].copy()
+    assert (A.ColorConvert(rows, cols, color="BGR", from_color="BINARY").filter(grey) == grey[..., None]).all()
+    assert (A.ColorConvert(rows, cols, color="HSV").filter(bgr) == O.bgr2hsv(bgr)).all()
+
+
+def test_cvt_color_refusals_carry_the_references_texts(A):
+    """ColorConvert.cpp:79-85 ("Nothing to be done ...") and Color.h:92-93 ("... not possible.")."""
+    from oat_amd import ffi
+    f3, f1 = np.zeros((4, 4, 3), np.uint8), np.zeros((4, 4), np.uint8)
+    for src, dst, text in (("BGR", "BGR", "Nothing to be done for BGR to BGR conversion."),
+                           ("GREY", "BINARY", "Nothing to be done for GREY to BINARY conversion."),
+                           ("HSV", "HSV", "Nothing to be done for HSV to HSV conversion."),
+                           ("HSV", "GREY", "Requested color conversion is not possible."),
+                           ("GREY", "HSV", "Requested color conversion is not possible.")):
+        with pytest.raises(ffi.OatGpuError, match=text):
+            A.ColorConvert(4, 4, color=dst, from_color=src).filter(f3 if src in ("BGR", "HSV") else f1)
+
+
+def test_grey_chain_from_bgr_frames(A):
+    """BGR camera -> framefilt col -C GREY -> framefilt mog -> posidet thresh (what SimpleThreshold.cpp:46 asks
+    for in front of it), stage by stage through the C ABI, against the oracle chain."""
+    from oat_amd.synth import SyntheticStream
+    rows, cols = 120, 200
+    st = SyntheticStream(rows, cols, 11, n_discs=1, radius=12)
+    col = A.ColorConvert(rows, cols, color="GREY")
+    hp = A.HotPath(rows, cols, n_streams=1, channels=1, adaptation_coeff=0.01, h_thresh=(30, 110), erode=3, dilate=7,
+                   area=(20.0, 1e5))
+    p = O.hsv_params(h_lo=30, h_hi=110, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    orc = O.Mog2(rows, cols, 1)
+    hits = 0
+    for t in range(20):
+        f = st.frame(t, with_discs=t > 0)
+        grey = col.filter(f)
+        assert (grey == O.bgr2grey(f)).all()
+        got = hp.track([grey])[0]
+        want, thr = O.chain_step(orc, grey, 0.01, p)
+        assert (hp.read_mask(1, 0) == thr).all(), t
+        _same_detection(got, want, t)
+        hits += got.position_valid
+    assert hits >= 15
+
+
 # --------------------------------------------------------------------- MOG2 --
 
 @pytest.mark.parametrize("shape", [(48, 64), (37, 101), (5, 3), (1, 1), (33, 256)])

@@ -155,6 +155,64 @@ def test_model_file_resumes_across_process_restarts(host_bins, tmp_path, fused):
     assert hits >= n - 3
 
 
+@pytest.mark.gpu
+def test_grey_component_pipeline_matches_oracle(host_bins, tmp_path):
+    """The thresh chain from a BGR camera, one OS process per component as the reference runs it:
+    frameserve -> framefilt col -C GREY -> framefilt mog -> posidet thresh (SimpleThreshold.cpp:46 wants GREY
+    frames, Source.h:300-313 refuses anything else "Maybe use oat-framefilt col?")."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 20
+    st = SyntheticStream(rows, cols, 4, n_discs=1, radius=14)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(n)]
+    raw = tmp_path / "frames.raw"
+    np.stack(frames).tofile(raw)
+    tag = "oat_t_" + uuid.uuid4().hex[:8]
+    a_raw, a_grey, a_filt, a_pos = (tag + s for s in ("raw", "grey", "filt", "pos"))
+    B = lambda x: os.path.join(host_bins, x)
+    reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([B("oat-posidet-hip"), "thresh", a_filt, a_pos, "-T", "[30,100]", "-e", "3", "-d", "7",
+                               "-a", "[20,100000]"]),
+             subprocess.Popen([B("oat-framefilt-hip"), "mog", a_grey, a_filt, "-a", "0.01"]),
+             subprocess.Popen([B("oat-framefilt-hip"), "col", a_raw, a_grey, "-C", "GREY"])]
+    time.sleep(3.0)
+    feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols", str(cols),
+                               "-n", str(n), "-r", "200"])
+    try:
+        out, _ = reader.communicate(timeout=180)
+        feeder.wait(timeout=60)
+        for p in procs:
+            p.wait(timeout=60)
+    finally:
+        for p in procs + [feeder, reader]:
+            if p.poll() is None:
+                p.kill()
+        subprocess.run([B("oat-clean-hip"), a_raw, a_grey, a_filt, a_pos], capture_output=True)
+    assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
+    got = [json.loads(l) for l in out.splitlines() if l.strip()]
+    assert len(got) == n
+    orc = O.Mog2(rows, cols, 1)
+    prm = O.hsv_params(h_lo=30, h_hi=100, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    hits = 0
+    for t, (f, g) in enumerate(zip(frames, got)):
+        want, _ = O.chain_step(orc, O.bgr2grey(f), 0.01, prm)
+        assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], t
+        if want["valid"]:
+            hits += 1
+            assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, t
+    assert hits >= n - 3
+
+
+def test_col_refuses_what_the_reference_refuses(host_bins):
+    """--color is required (ColorConvert.cpp:59-60 -> TOMLSanitize.h:199-200) and must name a colour (Color.h:65-77);
+    neither needs a GPU."""
+    exe = os.path.join(host_bins, "oat-framefilt-hip")
+    r = subprocess.run([exe, "col", "x_src", "x_snk"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 255 and "Required configuration value 'color' was not specified." in r.stderr
+    r = subprocess.run([exe, "col", "x_src", "x_snk", "-C", "RGB"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 255 and "Invalid color." in r.stderr
+
+
 def test_config_file_errors_are_the_references(host_bins, tmp_path):
     """-c FILE KEY (TOMLSanitize.h:73-118): bad pair, missing table, unknown key -> error exit, the
     reference's messages; none of this needs a GPU (options are parsed before any device work)."""

@@ -25,6 +25,18 @@ def test_bgr2hsv_matches_cvtcolor():
     assert (O.bgr2hsv(bgr) == cv2.cvtColor(bgr, cv2.COLOR_BGR2HSV)).all()
 
 
+def test_the_other_framefilt_col_conversions_match_cvtcolor():
+    """Color.h:45-51: BGR2GRAY, GRAY2BGR (any version) and HSV2BGR -- the latter only against OpenCV < 3.4, the
+    float routine the oracle restates; later versions convert in fixed point and differ by a level here and there."""
+    rng = np.random.default_rng(1)
+    px = rng.integers(0, 256, (256, 4096, 3), dtype=np.uint8)
+    assert (O.bgr2grey(px) == cv2.cvtColor(px, cv2.COLOR_BGR2GRAY)).all()
+    assert (O.grey2bgr(px[..., 0]) == cv2.cvtColor(px[..., 0].copy(), cv2.COLOR_GRAY2BGR)).all()
+    diff = np.abs(O.hsv2bgr(px).astype(int) - cv2.cvtColor(px, cv2.COLOR_HSV2BGR).astype(int)).max()
+    major, minor = (int(v) for v in cv2.__version__.split(".")[:2])
+    assert diff == 0 if (major, minor) < (3, 4) else diff <= 1, diff
+
+
 @pytest.mark.parametrize("k", [2, 3, 4, 7, 10])
 def test_rect_morphology_matches_cv(k):
     rng = np.random.default_rng(k)

@@ -257,3 +257,65 @@ def test_kalman_reference_quirks():
     assert seen == [True, True, True, True, False, False]       # 5th miss reaches the threshold
     o = k.filter(True, 300.0, 10.0)                  # re-initialised at the new measurement
     assert o["position_valid"] and (o["x"], o["y"], o["vx"], o["vy"]) == (300.0, 10.0, 0.0, 0.0)
+
+
+# ---- the other conversions of `framefilt col` (oat::color_conv_table, Color.h:45-51) ----
+
+def test_cvt_color_known_answers(golden_dir):
+    g = _load(golden_dir, "cvt_color_kat.json")
+    bgr = np.array(g["bgr"], np.uint8)[None]
+    assert O.bgr2grey(bgr)[0].tolist() == g["grey"]
+    hsv = np.array(g["hsv"], np.uint8)[None]
+    assert O.hsv2bgr(hsv)[0].tolist() == g["bgr_of_hsv"]
+    grey = np.arange(256, dtype=np.uint8)[None]
+    assert (O.grey2bgr(grey) == grey[..., None]).all()
+
+
+def test_cvt_color_exhaustive_against_the_numpy_restatement():
+    """All 2^24 inputs of BGR->GREY and HSV->BGR (h beyond 179 included): the C oracle against the vectorised
+    float32 / integer restatement in tests/golden/make_golden.py, written separately from it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    c = np.arange(256, dtype=np.uint8)
+    for a0 in range(0, 256, 32):                     # 8 slabs of 2^21 colours keep the float32 temporaries small
+        a, b, d = np.meshgrid(c[a0:a0 + 32], c, c, indexing="ij")
+        px = np.stack([a, b, d], -1).reshape(1, -1, 3)
+        assert (O.bgr2grey(px) == mg.bgr2grey_restated(px)).all()
+        assert (O.hsv2bgr(px) == mg.hsv2bgr_restated(px)).all()
+
+
+def test_cvt_color_properties():
+    c = np.arange(256, dtype=np.uint8)
+    b, g, r = np.meshgrid(c[::5], c[::3], c[::7], indexing="ij")
+    bgr = np.stack([b, g, r], -1).reshape(1, -1, 3)
+    grey = O.bgr2grey(bgr).astype(int)
+    assert (grey >= bgr.min(-1)).all() and (grey <= bgr.max(-1)).all()          # a convex combination
+    eq = np.stack([c, c, c], -1)[None]
+    assert (O.bgr2grey(eq)[0] == c).all()                                        # 1868 + 9617 + 4899 = 2^14
+    # BGR -> HSV -> BGR comes back within the quantisation of the 8-bit HSV grid (a hue step is 2 degrees)
+    back = O.hsv2bgr(O.bgr2hsv(bgr)).astype(int)
+    assert np.abs(back - bgr).max() <= 6
+    # s == 0 -> grey of value v whatever the hue; v == 0 -> black
+    hsv = np.stack([c, np.zeros_like(c), c[::-1]], -1)[None]
+    assert (O.hsv2bgr(hsv) == c[::-1][None, :, None]).all()
+    assert O.hsv2bgr(np.stack([c, c, np.zeros_like(c)], -1)[None]).max() == 0
+
+
+def test_cvt_color_table_is_the_references():
+    """oat::color_conv_table (Color.h:45-51): -1 nothing to be done, -2 not possible, else bytes per pixel."""
+    B, G, C3, H = O.BINARY, O.GREY, O.BGR, O.HSV
+    want = {(B, B): -1, (B, G): -1, (B, C3): 3, (B, H): -2,
+            (G, B): -1, (G, G): -1, (G, C3): 3, (G, H): -2,
+            (C3, B): 1, (C3, G): 1, (C3, C3): -1, (C3, H): 3,
+            (H, B): -2, (H, G): -2, (H, C3): 3, (H, H): -1}
+    rng = np.random.default_rng(5)
+    for (src, dst), code in want.items():
+        f = rng.integers(0, 256, (3, 5, 3) if src >= 2 else (3, 5)).astype(np.uint8)
+        rc, out = O.cvt_color(f, src, dst)
+        assert rc == code, (src, dst)
+        if code > 0:
+            ref = {(C3, H): O.bgr2hsv, (H, C3): O.hsv2bgr}.get((src, dst), O.bgr2grey if src == C3 else O.grey2bgr)(f)
+            assert out.shape == ref.shape and (out == ref).all()
