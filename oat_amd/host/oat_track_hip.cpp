@@ -20,6 +20,10 @@
 // pipelines), and only when the ring is full otherwise (frames waiting: copy of step t+1 overlaps the
 // kernels of step t, GPU-bound pipelines).  Options are the union of the three stock components'
 // (-a is mog's adaptation coefficient; the detector's area is --area).
+//
+// --thresh [lo,hi] selects the GREY chain instead:  framefilt mog -> posidet thresh  on SOURCEs that carry GREY
+// frames (a mono camera or `framefilt col -C GREY`; SimpleThreshold.cpp:46 requires them), the one-channel model
+// and the intensity window of SimpleThreshold.cpp:171-174 in the same fused launches.
 #include "component.hpp"
 #include <deque>
 #include <unistd.h>
@@ -60,6 +64,7 @@ public:
     double dt_{0.02}, timeout_{0.0}, sig_accel_{5.0}, sig_noise_{0.0};   // KalmanFilter2D.h:56-60
     std::string model_file_;        // --model-file: resume the MOG2 model(s) from / checkpoint to this file
     std::string mask_file_;         // --mask: `framefilt mask` fused in front of mog (FrameMasker.cpp:45-75)
+    bool grey_{false};              // --thresh: GREY frames, mog -> posidet thresh
     ~BatchedTracker() override
     {
         if (!model_file_.empty() && gpu_.ctx)
@@ -77,13 +82,14 @@ protected:
         for (int s = 0; s < n_; ++s) frame_sources_[s].touch(source_addresses_[s]);
         FrameParams p0{};
         for (int s = 0; s < n_; ++s) {
-            if (frame_sources_[s].connect(PIX_BGR) != SourceState::CONNECTED) return false;
+            if (frame_sources_[s].connect(grey_ ? PIX_GREY : PIX_BGR) != SourceState::CONNECTED) return false;
             const FrameParams p = frame_sources_[s].parameters();
             if (s == 0) p0 = p;
             else if (p.rows != p0.rows || p.cols != p0.cols)
                 throw std::runtime_error("all SOURCEs of one batched tracker must have the same frame geometry");
         }
         cfg_.rows = (int)p0.rows; cfg_.cols = (int)p0.cols; cfg_.n_streams = n_;
+        cfg_.channels = grey_ ? 1 : 3;
         if (cfg_.ring_depth < 2) cfg_.ring_depth = 2;
         gpu_.create(cfg_);
         if (!model_file_.empty())
@@ -187,18 +193,24 @@ int main(int argc, char **argv)
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
                          "       [--gpu-index N] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
+                         "       [--thresh [lo,hi]]   GREY SOURCEs: framefilt mog -> posidet thresh instead of the HSV chain\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
                          "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask"}, {"kalman"});
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh"}, {"kalman"});
         auto t = std::make_unique<BatchedTracker>(split_list(o.positional[0]), split_list(o.positional[1]));
         t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
         double a, b;
         if (o.arr2("h-thresh", a, b)) { t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b; }
         if (o.arr2("s-thresh", a, b)) { t->cfg_.s_lo = (int)a; t->cfg_.s_hi = (int)b; }
         if (o.arr2("v-thresh", a, b)) { t->cfg_.v_lo = (int)a; t->cfg_.v_hi = (int)b; }
+        if (o.arr2("thresh", a, b)) {                                 // SimpleThreshold.cpp:86-97
+            if (a < 0 || a > 256 || b < 0 || b > 256) throw std::runtime_error("Values of thresh should be between 0 and 256.");
+            t->grey_ = true;
+            t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b;              // the one-channel window lives in the h slot
+        }
         if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
         if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
         if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }

@@ -156,7 +156,8 @@ def test_model_file_resumes_across_process_restarts(host_bins, tmp_path, fused):
 
 
 @pytest.mark.gpu
-def test_grey_component_pipeline_matches_oracle(host_bins, tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_grey_component_pipeline_matches_oracle(host_bins, tmp_path, fused):
     """The thresh chain from a BGR camera, one OS process per component as the reference runs it:
     frameserve -> framefilt col -C GREY -> framefilt mog -> posidet thresh (SimpleThreshold.cpp:46 wants GREY
     frames, Source.h:300-313 refuses anything else "Maybe use oat-framefilt col?")."""
@@ -171,10 +172,14 @@ def test_grey_component_pipeline_matches_oracle(host_bins, tmp_path):
     a_raw, a_grey, a_filt, a_pos = (tag + s for s in ("raw", "grey", "filt", "pos"))
     B = lambda x: os.path.join(host_bins, x)
     reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
-    procs = [subprocess.Popen([B("oat-posidet-hip"), "thresh", a_filt, a_pos, "-T", "[30,100]", "-e", "3", "-d", "7",
-                               "-a", "[20,100000]"]),
-             subprocess.Popen([B("oat-framefilt-hip"), "mog", a_grey, a_filt, "-a", "0.01"]),
-             subprocess.Popen([B("oat-framefilt-hip"), "col", a_raw, a_grey, "-C", "GREY"])]
+    if fused:
+        procs = [subprocess.Popen([B("oat-track-hip"), a_grey, a_pos, "-a", "0.01", "--thresh", "[30,100]", "-e", "3",
+                                   "-d", "7", "--area", "[20,100000]"])]
+    else:
+        procs = [subprocess.Popen([B("oat-posidet-hip"), "thresh", a_filt, a_pos, "-T", "[30,100]", "-e", "3", "-d", "7",
+                                   "-a", "[20,100000]"]),
+                 subprocess.Popen([B("oat-framefilt-hip"), "mog", a_grey, a_filt, "-a", "0.01"])]
+    procs.append(subprocess.Popen([B("oat-framefilt-hip"), "col", a_raw, a_grey, "-C", "GREY"]))
     time.sleep(3.0)
     feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols", str(cols),
                                "-n", str(n), "-r", "200"])
