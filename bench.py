@@ -218,6 +218,7 @@ def cpu_baseline(name, frames_seq):
 
 
 LAB_CALM = False
+FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 
 def make_pool_dense(rows, cols, ns, nframes, rank, dev):
@@ -296,6 +297,7 @@ class Leg:
         self.pool = gen(wl["rows"], wl["cols"], self.ns, pool, rank, self.dev)
         torch.cuda.synchronize()
         self.hp = make_hotpath(wl, dev_index, dense=dense)
+        self.hp.set_fusion(FUSION)
         self.step = 0                    # frames consumed so far
         self.input_mode = input_mode
         self.host_pool = None
@@ -614,9 +616,13 @@ def main():
                          "frames old is a transient (SURVEY 8d measures behind a warm-up; with this reading of the mode "
                          "count the model keeps changing for a few hundred frames); 0 = as young as W makes it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fusion", type=int, default=2, choices=[1, 2],
+                    help="frames per launch of the fused per-pixel kernel on the pipelined path (oatgpu_set_fusion): 2 = "
+                         "two consecutive frames on one pass over the model (the library's default), 1 = one launch a frame")
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
-    global ALPHA, RESTORE, AGE, LAB_CALM
+    global ALPHA, RESTORE, AGE, LAB_CALM, FUSION
+    FUSION = args.fusion
     AGE = args.age
     LAB_CALM = args.lab_calm
     RESTORE = args.mog_restore_nmodes

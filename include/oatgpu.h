@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color */
+#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_profile.mog_frames */
 
 enum {
     OATGPU_OK = 0,
@@ -123,6 +123,8 @@ typedef struct oatgpu_profile {
     double event_pair_ms;      /* calibration: elapsed time of an event pair around an EMPTY
                                   kernel on the same HIP stream (what mog_ms contains per step
                                   besides kernel execution); measured at profile_enable */
+    int64_t mog_frames;        /* frames the `steps` measured launches of the fused kernel covered
+                                  (steps .. 2 * steps, see oatgpu_set_fusion)              */
 } oatgpu_profile;
 
 typedef struct oatgpu_ctx oatgpu_ctx;
@@ -149,6 +151,18 @@ void oatgpu_host_free(void *ptr);
 int oatgpu_set_stream(oatgpu_ctx *ctx, void *hip_stream);
 void *oatgpu_get_stream(oatgpu_ctx *ctx);
 int oatgpu_synchronize(oatgpu_ctx *ctx);
+
+/* Frames per launch of the fused per-pixel kernel on the pipelined path (oatgpu_track_enqueue[_dev],
+ * oatgpu_track_sequence_dev), 1 or 2; default 2.  The MOG2 update is a recurrence per pixel, so two
+ * consecutive frames of a stream can be taken on ONE pass over its model (kept in registers between them):
+ * with 2, an enqueue only registers its frame and the kernels are launched when the next frame is enqueued --
+ * or as soon as the frame's result is asked for (oatgpu_track_collect / oatgpu_track_ready reaching that
+ * frame) or any synchronous entry point runs, then for the one frame alone; a caller that collects every
+ * frame before it enqueues the next (oatgpu_track_batch*, a camera-bound component loop) never waits for a
+ * second frame.  Results, their order, the threshold images and the model are bit-identical either way
+ * (FrameFilter.cpp:59-98 / PositionDetector.cpp:58-99: one token out per token in, in order).
+ * The caller's frame of oatgpu_track_enqueue_dev must stay valid until its result was collected (as before). */
+int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
 /* Re-configure the detector between frames (what the reference's tuning GUI
  * mutates: HSVDetector.cpp:175-251). */

@@ -352,6 +352,10 @@ class HotPath(_Context):
     def synchronize(self):
         self._chk(self.lib.oatgpu_synchronize(self.ctx))
 
+    def set_fusion(self, frames_per_launch):
+        """Frames per launch of the fused per-pixel kernel on the pipelined path: 1 or 2 (default 2)."""
+        self._chk(self.lib.oatgpu_set_fusion(self.ctx, int(frames_per_launch)))
+
     def profile(self, every=1):
         """every = 0/False: off; 1/True: time every step; N: time every Nth step."""
         self._chk(self.lib.oatgpu_profile_enable(self.ctx, int(every)))
@@ -363,4 +367,4 @@ class HotPath(_Context):
         p = ffi.Profile()
         self._chk(self.lib.oatgpu_profile_read(self.ctx, C.byref(p)))
         return dict(steps=p.steps, mog_ms=p.mog_ms, morph_ms=p.morph_ms, blob_ms=p.blob_ms, total_ms=p.total_ms,
-                    event_pair_ms=p.event_pair_ms)
+                    event_pair_ms=p.event_pair_ms, mog_frames=p.mog_frames)

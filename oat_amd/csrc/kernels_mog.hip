@@ -307,9 +307,20 @@ struct Audit {
 // mask, K1b takes them compacted) -- K1a alone ran no faster than the whole one-kernel form (92 us): the kernel is
 // not bound by its second round trip but by the memory system (5.2 TB/s of real traffic on a device whose plain
 // copy reaches 6.6), and K1b added 50 us (profiles/r02_k1_split_rejected_kernel_trace.md).
-template <int CH, bool AUDIT, bool NTLD>
+//
+// Two frames a launch (NF == 2, "temporal fusion").  The model update is a recurrence per pixel; when the caller has
+// two consecutive frames of a stream in hand (the pipelined entry points with a ring of results, a recorded
+// sequence), ONE pass over the model takes both: the mixture stays in registers between the frames, so the 44 B/px an
+// everyday model moves per frame (202 B/px a dense one) are moved once per TWO frames and only the 3 B/px of the
+// second frame are added.  Same arithmetic in the same order -- the model after the launch and both threshold
+// images are bit-identical to two single-frame launches (state-parity tests run both forms).  What the second
+// frame needs beyond the first's registers: a lane that matched mode 0 as background in frame 1 never loaded the
+// records of its later slots; if it is a "full" lane in frame 2 it loads them then (they are untouched: such a lane
+// changes slot 0 only).  Weights are always current in registers (a slot not loaded was dead = 0 and stays 0).
+template <int CH, bool AUDIT, bool NTLD, int NF>
 __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
+    static_assert(NF == 1 || !AUDIT, "the traffic audit counts single-frame launches");
     Audit<AUDIT> au;
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
     // 79 % VALU-busy at 370 VALU instructions per wave before, profiles/r02_k1_sq_counters_before.md): every plane
@@ -423,13 +434,20 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
         if (CH == 3) { gg = frame[fj + 1]; r = frame[fj + 2]; }
         au.run(valid, CH, false);
     }
+    unsigned px2 = 0;                             // NF == 2: the second frame's pixel, packed b | g << 8 | r << 16
+    if (NF == 2) {
+        const uint8_t *frame2 = a.frames2 + (size_t)s * npx * CH;
+        const unsigned fj = valid ? fi : 0u;
+        px2 = frame2[fj];
+        if (CH == 3) px2 |= (unsigned)frame2[fj + 1] << 8 | (unsigned)frame2[fj + 2] << 16;
+    }
     if (!active) return;
 
     // `framefilt mask` placed before mog (FrameMasker.cpp:71-75: frame.setTo(0, roi_mask == 0)):
     // one bit per pixel, one word per wave.
     if (a.roi_bits) {
         const u64 rw = a.roi_bits[(size_t)s * nwords + widx];
-        if (!((rw >> lpos) & 1ull)) { b = 0; gg = 0; r = 0; }
+        if (!((rw >> lpos) & 1ull)) { b = 0; gg = 0; r = 0; px2 = 0; }
     }
 
     const int nold = cnt & kCountMask;
@@ -497,14 +515,59 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
         thr = work && b >= a.rp.lo[0] && b <= a.rp.hi[0];
     }
 
+    bool full_any = full;
+    int nlive = max(nold, nnew);
+    if (NF == 2) {
+        // ---- the second frame, on the registers the first one left ----
+        const u64 word1 = __ballot(thr);
+        if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * nwords + widx] = word1;
+        b = (int)(px2 & 255u); gg = (int)((px2 >> 8) & 255u); r = (int)(px2 >> 16);
+        const int nold2 = nnew;
+        const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
+        PxLoop lq{false, false, nold2, 0.f};
+        bool wchg2 = false;
+        if (valid) mog2_mode<CH, 0>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+        const bool full2 = valid && !(lq.fits && lq.background);
+        // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
+        const bool need2 = full2 && !full;
+#pragma unroll
+        for (int k = 1; k < kMaxMix; ++k)
+            if (need2 && k < nold2) ld_rec(k, pm.v[k], pm.m[k]);
+#pragma unroll
+        for (int k = 1; k < kMaxMix; ++k)
+            asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
+        int mask2 = 0, nnew2 = nold2;
+        if (work) {
+            mog2_mode<CH, 1>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 2>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 3>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 4>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mask2 = mog2_finish<CH>(pm, lq, nold2, nnew2, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, dvm, wchg2);
+        }
+        if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
+        if (CH == 3) {
+            thr = work && in_range3(0, 0, 0, a.rp);
+            if (mask2 != 0) {
+                int hh, ss, vv;
+                bgr2hsv_inline(b, gg, r, hh, ss, vv);
+                thr = work && in_range3(hh, ss, vv, a.rp);
+            }
+        } else {
+            thr = work && b >= a.rp.lo[0] && b <= a.rp.hi[0];
+        }
+        wchg = wchg || wchg2;
+        full_any = full || full2;
+        nlive = max(nlive, nnew2);
+        nnew = nnew2;
+    }
+
     // ---- store back only what changed (values not stored are bit-identical in HBM) ----
     // Weights of slot k >= 1 can only have changed on a full lane (anything goes there) or where the
     // slot was live (decay / renormalisation); a dead slot on a matched lane was 0 and still is.
-    const int nlive = max(nold, nnew);
     int newcnt = nnew;
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
-        const bool was_live = k == 0 || full || ((cnt >> (kLiveShift + k)) & 1);
+        const bool was_live = k == 0 || full_any || ((cnt >> (kLiveShift + k)) & 1);
         const bool sw = work && wchg && k < nlive && was_live, svm = (dvm >> k) & 1u;
         if (sw) STW(k, pm.w[k]);
         if (svm) st_rec(k, pm.v[k], pm.m[k]);
@@ -517,7 +580,8 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
     AU_B(sc, true);
 
     const u64 word = __ballot(thr);
-    if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * nwords + widx] = word;
+    u64 *const thr_out = NF == 2 ? a.thr_bits2 : a.thr_bits;
+    if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
     au.run(a.thr_bits && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
 #undef LDW
@@ -558,24 +622,32 @@ void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 
-template <int CH, bool AUDIT, bool NTLD>
+template <int CH, bool AUDIT, bool NTLD, int NF>
 static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD>), grid, dim3(256), 0, st, g, a, first_stream);
+    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF>), grid, dim3(256), 0, st, g, a, first_stream);
 }
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
-    if (a.audit) {                       // (the audit counts bytes, not cache behaviour: default-policy loads)
-        if (a.channels == 1) launch_mog_ch<1, true, false>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, true, false>(g, a, first_stream, n_streams, st);
+    if (a.frames2) {                     // two frames a launch (never audited, never fresh: the caller's business)
+        if (a.nt_loads) {
+            if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st);
+            else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st);
+        } else {
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st);
+            else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st);
+        }
+    } else if (a.audit) {                // (the audit counts bytes, not cache behaviour: default-policy loads)
+        if (a.channels == 1) launch_mog_ch<1, true, false, 1>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, true, false, 1>(g, a, first_stream, n_streams, st);
     } else if (a.nt_loads) {
-        if (a.channels == 1) launch_mog_ch<1, false, true>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false, true>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st);
     } else {
-        if (a.channels == 1) launch_mog_ch<1, false, false>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false, false>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st);
     }
 }
 

@@ -37,7 +37,7 @@ static inline const char *measure_env(const char *name)
 #endif
 }
 
-struct ProfStep { hipEvent_t e[5]; };
+struct ProfStep { hipEvent_t e[5]; int frames = 1; };   // frames: what the K1 launch between e[0] and e[1] covered
 struct Rate { float alphaT, alpha1, prune; int fresh; };   // A: K1 begin/end; B: back-half begin, after erode, end
 
 struct oatgpu_ctx {
@@ -81,6 +81,15 @@ struct oatgpu_ctx {
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
     int last_q = 0;
     std::string err;
+    // Temporal fusion (kernels_mog.hip "Two frames a launch"): with fuse == 2 a pipelined enqueue only REGISTERS its
+    // frame (ring slot, counters); the kernels go out when the next frame is enqueued -- K1 once for both -- or when
+    // somebody needs the frame's result or the model (collect / ready of that very frame, every synchronous entry
+    // point, destroy), then for the one frame alone.  Results, their order and the model are those of one launch a frame.
+    struct FrameJob { const void *frames = nullptr; double lr = 0.0; hipEvent_t ready = nullptr; int slot = 0; };
+    int fuse = 2;
+    bool pend_valid = false;
+    FrameJob pend;
+    unsigned long long launched_total = 0;            // frames whose kernels are out (<= enq_total)
 
     // device memory
     float *state = nullptr;
@@ -463,6 +472,7 @@ extern "C" void oatgpu_destroy(oatgpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->cfg.device);
+    c->pend_valid = false;            // a registered frame nobody collected: nothing to launch for
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) hipStreamSynchronize(c->stream_b[q]);
     free_all(c);
@@ -493,9 +503,11 @@ extern "C" void *oatgpu_host_alloc(size_t bytes)
 }
 extern "C" void oatgpu_host_free(void *ptr) { if (ptr) hipHostFree(ptr); }
 
+static int flush_pending(oatgpu_ctx *c);
 extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
 {
     if (!c) return OATGPU_E_INVALID;
+    { const int frc = flush_pending(c); if (frc) return frc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -504,15 +516,24 @@ extern "C" int oatgpu_set_stream(oatgpu_ctx *c, void *s)
     return OATGPU_OK;
 }
 extern "C" void *oatgpu_get_stream(oatgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
+static int quiesce(oatgpu_ctx *c);
 extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
+    return quiesce(c);
+}
+extern "C" int oatgpu_set_fusion(oatgpu_ctx *c, int32_t frames_per_launch)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (frames_per_launch != 1 && frames_per_launch != 2) return fail(c, OATGPU_E_INVALID, "frames_per_launch must be 1 or 2");
+    const int rc = quiesce(c);
+    if (rc) return rc;
+    c->fuse = frames_per_launch;
     return OATGPU_OK;
 }
 
 static int quiesce(oatgpu_ctx *c);
+static int flush_pending(oatgpu_ctx *c);
 
 extern "C" int oatgpu_set_detector(oatgpu_ctx *c, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
                                    int32_t v_lo, int32_t v_hi, int32_t erode, int32_t dilate,
@@ -555,8 +576,12 @@ static u64 *thr_buf(oatgpu_ctx *c, int parity)
 
 // The single-stage calls are synchronous and share scratch with the pipelined path:
 // wait until both HIP streams have drained.
+static int flush_pending(oatgpu_ctx *c);
+
 static int quiesce(oatgpu_ctx *c)
 {
+    const int frc = flush_pending(c);
+    if (frc) return frc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     return OATGPU_OK;
@@ -919,6 +944,7 @@ static void prof_fold(oatgpu_ctx *c)
         hipEventElapsedTime(&d, p.e[3], p.e[4]);   // dilate + labelling + sums + selection (stream B)
         hipEventElapsedTime(&t, p.e[0], p.e[4]);   // latency of the frame through both streams
         c->prof_sum.steps += 1;
+        c->prof_sum.mog_frames += p.frames;
         c->prof_sum.mog_ms += a; c->prof_sum.morph_ms += b; c->prof_sum.blob_ms += d; c->prof_sum.total_ms += t;
     }
     c->prof_used = 0;
@@ -973,20 +999,12 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
     return enqueue_frames(c, dst, lr, c->copy_ev[slot]);
 }
 
-static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready)
+// The kernels of one frame (nj == 1) or of two consecutive frames (nj == 2: K1 once for both where the streams'
+// learning-rate schedules allow, then each frame's back half on its own B stream).
+static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
 {
-    if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
-    if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
-    HIPCHK(c, hipSetDevice(c->cfg.device));
     const int n = c->cfg.n_streams;
-    const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
-    // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
-    // fewer then: the copy stream sits on the last B stream's hardware queue (see acquire_streams)
-    const int nbe = (frames_ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
-    const int q = slot % nbe;
-    const int k = slot;                              // threshold-bit buffer of this frame
-    hipStream_t A = c->stream, B = c->serial ? c->stream : c->stream_b[q];
-    c->b_used[q] = true;
+    hipStream_t A = c->stream;
 
     ProfStep *ps = nullptr;
     if (c->prof && (c->prof_tick++ % (unsigned long long)c->prof_every) == 0) {
@@ -999,33 +1017,51 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
             }
         }
         ps = &c->prof_steps[c->prof_used++];
+        ps->frames = nj;
     }
 
-    // Stream A: the fused per-pixel kernel of THIS frame may start while the B streams are still
+    // Stream A: the fused per-pixel kernel of THIS step may start while the B streams are still
     // analysing earlier frames' masks.  It writes the threshold buffer of its own ring slot, whose
     // previous reader finished before that slot's result was collected: nothing to wait for.
-    if (frames_ready) HIPCHK(c, hipStreamWaitEvent(A, frames_ready, 0));
+    for (int i = 0; i < nj; ++i)
+        if (j[i].ready) HIPCHK(c, hipStreamWaitEvent(A, j[i].ready, 0));
     if (ps) HIPCHK(c, hipEventRecord(ps->e[0], A));
 
-    // every camera stream advances one frame; launches are batched while the streams share a
+    // every camera stream advances one frame per job; launches are batched while the streams share a
     // learning-rate schedule (they do unless the single-stage calls were used unevenly)
     std::vector<Rate> &rates = c->rates_scratch;
-    rates.resize(n);
-    for (int s = 0; s < n; ++s) rates[s] = mog_begin(c, s, lr);
+    rates.resize((size_t)n * nj);
+    for (int i = 0; i < nj; ++i)
+        for (int s = 0; s < n; ++s) rates[(size_t)i * n + s] = mog_begin(c, s, j[i].lr);
+    auto same = [&](int s1, int s0) {
+        for (int i = 0; i < nj; ++i)
+            if (memcmp(&rates[(size_t)i * n + s1], &rates[(size_t)i * n + s0], sizeof(Rate)) != 0) return false;
+        return true;
+    };
     int s0 = 0;
     while (s0 < n) {
         int s1 = s0 + 1;
-        while (s1 < n && memcmp(&rates[s1], &rates[s0], sizeof(Rate)) == 0) ++s1;
-        MogLaunch a = mog_launch_base(c, (const uint8_t *)frames_dev, rates[s0]);
-        a.thr_bits = thr_buf(c, k);
-        launch_mog_fused(c->g, a, s0, s1 - s0, A);
+        while (s1 < n && same(s1, s0)) ++s1;
+        const bool pair = nj == 2 && !rates[s0].fresh && !rates[(size_t)n + s0].fresh && !c->audit_on;
+        for (int i = 0; i < (pair ? 1 : nj); ++i) {
+            MogLaunch a = mog_launch_base(c, (const uint8_t *)j[i].frames, rates[(size_t)i * n + s0]);
+            a.thr_bits = thr_buf(c, j[i].slot);
+            if (pair) {
+                const Rate &r2 = rates[(size_t)n + s0];
+                a.frames2 = (const uint8_t *)j[1].frames;
+                a.thr_bits2 = thr_buf(c, j[1].slot);
+                a.alphaT2 = r2.alphaT; a.alpha12 = r2.alpha1; a.prune2 = r2.prune;
+            }
+            launch_mog_fused(c->g, a, s0, s1 - s0, A);
+        }
         s0 = s1;
     }
     HIPCHK(c, hipGetLastError());
     if (ps) HIPCHK(c, hipEventRecord(ps->e[1], A));
-    {   // model density -> cache policy of the next launches: probes at frames 8, 16, 32, then every 64th; each
+    for (int i = 0; i < nj; ++i) {
+        // model density -> cache policy of the next launches: probes at frames 8, 16, 32, then every 64th; each
         // probe's numbers are read when the NEXT one is launched (it finished long ago: the ring is a few deep)
-        const unsigned long long t = c->enq_total;
+        const unsigned long long t = c->launched_total + (unsigned long long)i;
         if ((t >= 8 && t < 64 && (t & (t - 1)) == 0) || (t >= 64 && (t & 63) == 0)) {
             const int ds = (int)(c->dens_probes & 1);
             const unsigned *prev = c->dens_host + 2 * (ds ^ 1);
@@ -1034,45 +1070,90 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
             c->dens_probes++;
         }
     }
-    if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
-        HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
-        c->enq_total++;
-        c->ring_count++;
-        return OATGPU_OK;
-    }
-    HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
+    c->launched_total += (unsigned long long)nj;
 
-    // Stream B[q]: morphology + blob analysis of this frame.
-    HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
-    if (c->use_graph && !c->back_graph[slot]) {
-        c->back_graph[slot] = capture_back_half(c, slot, B);
-        if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
+    for (int i = 0; i < nj; ++i) {
+        const int slot = j[i].slot;
+        // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
+        // fewer then: the copy stream sits on the last B stream's hardware queue (see acquire_streams)
+        const int nbe = (j[i].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
+        const int q = slot % nbe;
+        const int k = slot;                              // threshold-bit buffer of this frame
+        hipStream_t B = c->serial ? c->stream : c->stream_b[q];
+        c->b_used[q] = true;
+        ProfStep *pb = i == 0 ? ps : nullptr;           // the back half of the step's first frame is the sampled one
+        if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
+            HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
+            continue;
+        }
+        HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
+
+        // Stream B[q]: morphology + blob analysis of this frame.
+        HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
+        if (c->use_graph && !c->back_graph[slot]) {
+            c->back_graph[slot] = capture_back_half(c, slot, B);
+            if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
+        }
+        if (c->use_graph && c->back_graph[slot]) {
+            if (pb) { HIPCHK(c, hipEventRecord(pb->e[2], B)); HIPCHK(c, hipEventRecord(pb->e[3], B)); }
+            HIPCHK(c, hipGraphLaunch(c->back_graph[slot], B));
+            const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+            const bool ero = c->cfg.erode > 1, fused = ero && rowscan_lds_bytes(c->g, dil) <= kRowscanLdsMax;
+            c->last_morph = (dil || fused) ? c->bb[q].morph : (ero ? c->bb[q].tmp : thr_buf(c, k));
+            c->last_fin = c->bb[q].fin;
+        } else {
+            if (pb) HIPCHK(c, hipEventRecord(pb->e[2], B));
+            const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;   // (the position filter is sequential: no repairs behind it)
+            c->slot_spec[slot] = mode == kBlobSpec;
+            c->slot_q[slot] = (char)q;
+            int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode);
+            if (rc) return rc;
+        }
+        if (c->kal_on) {
+            KalmanLaunch kl = c->kal;
+            kl.ticket = c->kal_ticket++;
+            launch_kalman(kl, c->res_dev + (size_t)slot * n, n, B);
+            HIPCHK(c, hipGetLastError());
+        }
+        c->slot_filtered[slot] = c->kal_on;
+        if (pb) HIPCHK(c, hipEventRecord(pb->e[4], B));
+        HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
+        c->last_q = k;
     }
-    if (c->use_graph && c->back_graph[slot]) {
-        if (ps) { HIPCHK(c, hipEventRecord(ps->e[2], B)); HIPCHK(c, hipEventRecord(ps->e[3], B)); }
-        HIPCHK(c, hipGraphLaunch(c->back_graph[slot], B));
-        const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-        const bool ero = c->cfg.erode > 1, fused = ero && rowscan_lds_bytes(c->g, dil) <= kRowscanLdsMax;
-        c->last_morph = (dil || fused) ? c->bb[q].morph : (ero ? c->bb[q].tmp : thr_buf(c, k));
-        c->last_fin = c->bb[q].fin;
+    return OATGPU_OK;
+}
+
+// launch what oatgpu_track_enqueue[_dev] only registered
+static int flush_pending(oatgpu_ctx *c)
+{
+    if (!c->pend_valid) return OATGPU_OK;
+    c->pend_valid = false;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return launch_jobs(c, &c->pend, 1);
+}
+
+static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready)
+{
+    if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    oatgpu_ctx::FrameJob cur;
+    cur.frames = frames_dev; cur.lr = lr; cur.ready = frames_ready;
+    cur.slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
+    // two frames a launch: only where a second frame can be outstanding, and not under the measurement switches
+    const bool may_fuse = c->fuse == 2 && c->cfg.ring_depth >= 2 && !c->use_graph && !c->serial && !c->expt && !c->audit_on;
+    int rc = OATGPU_OK;
+    if (c->pend_valid) {
+        const oatgpu_ctx::FrameJob two[2] = {c->pend, cur};
+        c->pend_valid = false;
+        rc = launch_jobs(c, two, 2);
+    } else if (may_fuse) {
+        c->pend = cur;
+        c->pend_valid = true;
     } else {
-        if (ps) HIPCHK(c, hipEventRecord(ps->e[2], B));
-        const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;   // (the position filter is sequential: no repairs behind it)
-        c->slot_spec[slot] = mode == kBlobSpec;
-        c->slot_q[slot] = (char)q;
-        int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, ps ? ps->e[3] : nullptr, -1, -1, mode);
-        if (rc) return rc;
+        rc = launch_jobs(c, &cur, 1);
     }
-    if (c->kal_on) {
-        KalmanLaunch kl = c->kal;
-        kl.ticket = c->kal_ticket++;
-        launch_kalman(kl, c->res_dev + (size_t)slot * n, n, B);
-        HIPCHK(c, hipGetLastError());
-    }
-    c->slot_filtered[slot] = c->kal_on;
-    if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
-    HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
-    c->last_q = k;
+    if (rc) return rc;
     c->enq_total++;
     c->ring_count++;
     return OATGPU_OK;
@@ -1083,6 +1164,10 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->ring_count == 0) return fail(c, OATGPU_E_RING_EMPTY, "nothing outstanding");
     const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
+    if (c->pend_valid && c->pend.slot == slot) {          // the frame wanted is still only registered: launch it alone
+        const int frc = flush_pending(c);
+        if (frc) return frc;
+    }
     HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
     {   // speculation bookkeeping (see lds_spec)
@@ -1131,6 +1216,10 @@ extern "C" int oatgpu_track_ready(oatgpu_ctx *c)
     if (!c) return OATGPU_E_INVALID;
     if (c->ring_count == 0) return 0;
     const int slot = (int)(c->col_total % (unsigned long long)c->ring_slots);
+    if (c->pend_valid && c->pend.slot == slot) {          // somebody is waiting for this very frame: send it off
+        const int frc = flush_pending(c);
+        if (frc) return frc;
+    }
     const hipError_t e = hipEventQuery(c->ring_ev[slot]);
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) return 0;
@@ -1429,6 +1518,7 @@ extern "C" int oatgpu_traffic_read(oatgpu_ctx *c, oatgpu_traffic *out)
 extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
 {
     if (!c) return OATGPU_E_INVALID;
+    { const int frc = flush_pending(c); if (frc) return frc; }
     if (!on) prof_fold(c);
     if (on && !c->prof) {
         // calibrate: what an event pair measures on stream A around a launch that does nothing
@@ -1457,6 +1547,7 @@ extern "C" int oatgpu_profile_enable(oatgpu_ctx *c, int32_t on)
 extern "C" int oatgpu_profile_read(oatgpu_ctx *c, oatgpu_profile *out)
 {
     if (!c || !out) return OATGPU_E_INVALID;
+    { const int frc = flush_pending(c); if (frc) return frc; }
     prof_fold(c);
     *out = c->prof_sum;
     out->event_pair_ms = c->event_pair_ms;
@@ -1465,6 +1556,7 @@ extern "C" int oatgpu_profile_read(oatgpu_ctx *c, oatgpu_profile *out)
 extern "C" int oatgpu_profile_reset(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
+    { const int frc = flush_pending(c); if (frc) return frc; }
     prof_fold(c);
     c->prof_sum = oatgpu_profile{};
     return OATGPU_OK;

@@ -88,6 +88,12 @@ struct MogLaunch {
     const u64 *roi_bits;     // [n][Palloc/64] region-of-interest bits (framefilt mask fused in) or nullptr
     float alphaT, alpha1, prune;
     int fresh;               // 1: model is (re)initialised this frame -> no modes
+    // Temporal fusion (kernels_mog.hip "Two frames a launch"): frames2 != nullptr -> the launch advances every
+    // stream by TWO frames -- `frames` then `frames2` -- on ONE pass over the model; thr_bits2 takes the second
+    // frame's threshold words, the *2 rates are the second frame's.  Never with fresh, out_bgr / out_mask or audit.
+    const uint8_t *frames2;
+    u64 *thr_bits2;
+    float alphaT2, alpha12, prune2;
     int nt_loads;            // 1: slots 1..4 are LOADED with the streaming cache policy too (dense models; kernels_mog.hip)
     unsigned long long *audit;   // nullptr, or 8 device counters: the traffic-audit instantiation runs (oatgpu_traffic_audit)
     MogParams mp;

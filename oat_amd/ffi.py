@@ -41,7 +41,8 @@ class Position(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("steps", C.c_int64), ("mog_ms", C.c_double), ("morph_ms", C.c_double),
-                ("blob_ms", C.c_double), ("total_ms", C.c_double), ("event_pair_ms", C.c_double)]
+                ("blob_ms", C.c_double), ("total_ms", C.c_double), ("event_pair_ms", C.c_double),
+                ("mog_frames", C.c_int64)]
 
 
 class Traffic(C.Structure):
@@ -84,6 +85,7 @@ SIGNATURES = {
     "oatgpu_mog_filter": (C.c_int, [_ctx, C.c_int32, _u8p, _u8p, C.c_double]),
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
     "oatgpu_cvt_color": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p, _u8p]),
+    "oatgpu_set_fusion": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_diff": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
