@@ -48,6 +48,8 @@ import torch
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PIXEL = 205           # 3 B BGR + 101 B model read + 101 B model write
+FRAME_BYTES_PER_PIXEL = 3       # ... of which the frame
+MODEL_BYTES_PER_PIXEL = 202     # ... and the model, read and written
 
 WORKLOADS = {
     "1080p1": dict(rows=1080, cols=1920, streams=1, erode=3, dilate=7),
@@ -465,7 +467,10 @@ def audit(leg, steps=6):
     t = leg.hp.traffic_read()
     leg.hp.traffic_audit(False)
     px = max(t["pixels"], 1)
+    # `pixels` counts the pixels of every audited LAUNCH; a launch covers frames_per_launch frames (oatgpu_set_fusion),
+    # so the *_B_per_px figures below are per pixel and launch -- per pixel and FRAME they are that / frames_per_launch
     return dict(steps=steps, pixels=t["pixels"], launches=t["launches"],
+                frames_per_launch=steps * leg.ns * leg.wl["rows"] * leg.wl["cols"] / px,
                 useful_read_B_per_px=t["lane_bytes_read"] / px, useful_write_B_per_px=t["lane_bytes_written"] / px,
                 sector32_read_B_per_px=t["sector32_bytes_read"] / px, sector32_write_B_per_px=t["sector32_bytes_written"] / px,
                 sector64_read_B_per_px=t["sector64_bytes_read"] / px, sector64_write_B_per_px=t["sector64_bytes_written"] / px)
@@ -504,7 +509,8 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
     tmp = tempfile.mkdtemp(prefix="oat_pmc_", dir="/tmp")
     cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--steps", str(K), "--warmup", str(W),
-           "--age", str(AGE if not dense else 60), "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA)]
+           "--age", str(AGE if not dense else 60), "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA),
+           "--fusion", str(FUSION)]
     if dense:
         cmd.append("--dense-model")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -724,24 +730,32 @@ def main():
     fps = total_streams * K / elapsed
     px_per_launch = rows * cols * ns
     mog_ms, mog_ms_raw = k1_ms(prof)
+    fpl = prof["mog_frames"] / max(prof["steps"], 1)          # frames a launch of the per-pixel kernel covered (1..2)
     pool_host0 = [leg.pool[leg.pool_index(i)][0].cpu().numpy() for i in range(8)]
     benched = dict(workload=args.workload + (" --dense-model" if args.dense_model else ""), avg_launch_ms=mog_ms,
                    avg_launch_ms_raw_events=mog_ms_raw, empty_event_pair_ms=prof["event_pair_ms"],
-                   px_per_launch=px_per_launch,
-                   algorithmic_rate_GBps=BYTES_PER_PIXEL * px_per_launch / (mog_ms * 1e-3) / 1e9,
-                   note="algorithmic_rate = 205 B/px / kernel time; on sparse models it exceeds the pin rate because the "
-                        "kernel moves only what the arithmetic can depend on -- it is NOT a roofline fraction")
+                   px_per_launch=px_per_launch, frames_per_launch=fpl, k_mog_fused_ms_per_frame=mog_ms / fpl,
+                   note="a launch takes frames_per_launch consecutive frames of every stream on ONE pass over the model "
+                        "(oatgpu_set_fusion); avg_launch_ms, traffic and moved_bytes_per_px are per LAUNCH, "
+                        "moved_bytes_per_px_frame = that / frames_per_launch; useful_* / requested_* are the kernel's own "
+                        "audit of ONE-frame launches")
     if aud:
-        benched.update(useful_bytes_per_px=aud["useful_read_B_per_px"] + aud["useful_write_B_per_px"],
+        # the audit counts ONE-frame launches (the library does not pair frames while it is on): what one pass over the
+        # model for one frame asks for.  A two-frame launch asks for at least that + the second frame's 3 B/px and
+        # threshold words (a lower bound: lanes that only become "full" in the second frame load their records late,
+        # and more planes end up changed).
+        u1 = aud["useful_read_B_per_px"] + aud["useful_write_B_per_px"]
+        benched.update(useful_bytes_per_px=u1,
                        requested_sector32_bytes_per_px=aud["sector32_read_B_per_px"] + aud["sector32_write_B_per_px"],
                        requested_sector64_bytes_per_px=aud["sector64_read_B_per_px"] + aud["sector64_write_B_per_px"],
+                       useful_bytes_per_px_launch_lower_bound=u1 + (fpl - 1.0) * (FRAME_BYTES_PER_PIXEL + 0.125),
                        audit=aud, mode_histogram=hist)
     # ---- the leg where the algorithmic bytes really move: 4K, all five modes live on every pixel ----
     dense = None
     if solo and not args.no_dense_leg and args.input == "device":
         try:
             if args.dense_model and args.workload == "4k1":
-                dense = dict(avg_launch_ms=mog_ms, px_per_launch=px_per_launch, steps=K, audit=aud)
+                dense = dict(avg_launch_ms=mog_ms, px_per_launch=px_per_launch, steps=K, audit=aud, frames_per_launch=fpl)
             else:
                 dl = Leg("4k1", local_rank, rank, dense=True, pool=10)
                 # 1 200 untimed warm-up steps (~0.35 s): a device that has just become busy runs this leg 10-15 %
@@ -755,10 +769,22 @@ def main():
                                                      age_frames=60, export=False)
                 d_aud = audit(dl, 4)
                 dense = dict(avg_launch_ms=k1_ms(d_prof)[0], px_per_launch=3840 * 2160, steps=300,
-                             ms_per_step=d_el / 300 * 1e3, audit=d_aud, burst_avg_launch_ms=k1_ms(b_prof)[0])
+                             ms_per_step=d_el / 300 * 1e3, audit=d_aud, burst_avg_launch_ms=k1_ms(b_prof)[0],
+                             frames_per_launch=d_prof["mog_frames"] / max(d_prof["steps"], 1))
                 dl.close()
                 del dl
                 torch.cuda.empty_cache()
+                if dense["frames_per_launch"] > 1.5:
+                    # the same leg with one frame a launch (oatgpu_set_fusion(1): what a caller that collects every
+                    # frame before the next gets, and SURVEY 8d's 205 B/px case), sustained state as above
+                    d1 = Leg("4k1", local_rank, rank, dense=True, pool=10)
+                    d1.hp.set_fusion(1)
+                    _, _, p1, _, _, _ = timed_run(d1, 300, 1200, lambda: (d1.hp.synchronize(), torch.cuda.synchronize()), 2,
+                                                  age_frames=60, export=False)
+                    dense["one_frame_avg_launch_ms"] = k1_ms(p1)[0]
+                    d1.close()
+                    del d1
+                    torch.cuda.empty_cache()
         except Exception as e:
             log("dense leg failed:", e)
 
@@ -777,11 +803,13 @@ def main():
         w_ = WORKLOADS[er["name"]]
         ppl = w_["rows"] * w_["cols"] * w_["streams"]
         e_k1 = k1_ms(er["prof"])[0]
+        e_fpl = er["prof"]["mog_frames"] / max(er["prof"]["steps"], 1)
         extra[er["name"]] = dict(value=w_["streams"] * er["K"] / er["el"], unit="frames/s", steps=er["K"], warmup=er["W"],
                                  model_age_frames=er["handover"], ms_per_step=er["el"] / er["K"] * 1e3, k_mog_fused_ms=e_k1,
+                                 frames_per_launch=e_fpl, k_mog_fused_ms_per_frame=e_k1 / e_fpl, px_per_launch=ppl,
                                  useful_bytes_per_px=er["aud"]["useful_read_B_per_px"] + er["aud"]["useful_write_B_per_px"],
                                  requested_sector32_bytes_per_px=er["aud"]["sector32_read_B_per_px"] + er["aud"]["sector32_write_B_per_px"],
-                                 algorithmic_rate_GBps=BYTES_PER_PIXEL * ppl / (e_k1 * 1e-3) / 1e9, parity=e_par)
+                                 audit_frames_per_launch=er["aud"]["frames_per_launch"], parity=e_par)
         er["leg"].close()
         er["models"] = er["leg"] = None
     extra_runs = []
@@ -791,44 +819,68 @@ def main():
     if solo and dense and not args.no_pmc and args.input == "device":
         t0 = time.perf_counter()
         da = dense.get("audit")
+        # calibration of the two counters against the kernel's own byte count: only where the audited launches and the
+        # profiled ones are the same kind (the audit counts one-frame launches)
         aud_bytes = ((da["sector32_read_B_per_px"] * dense["px_per_launch"],
-                      da["sector32_write_B_per_px"] * dense["px_per_launch"]) if da else None)
+                      da["sector32_write_B_per_px"] * dense["px_per_launch"])
+                     if da and abs((dense.get("frames_per_launch") or 1.0) - da.get("frames_per_launch", 1.0)) < 1e-6 else None)
         pmc = pmc_traffic(args.workload, W, aud_bytes, args.dense_model)
         log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
 
     roofline = {"bound": "hbm", "kernel": "k_mog_fused", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "measured_stream_read_GBps": hbm_read, "measured_stream_copy_GBps": hbm_copy}
     if dense:
-        a_dense = BYTES_PER_PIXEL * dense["px_per_launch"] / (dense["avg_launch_ms"] * 1e-3) / 1e9
+        # What a launch has to move, as executed: frames_per_launch frames in (3 B/px each), the model in and out ONCE
+        # (101 + 101 B/px).  With one frame a launch that is SURVEY 8d's 205 B/px; with two frames a launch 208 B/px
+        # for two frames -- the kernel keeps the mixture in registers between the frames, which is the point of it.
+        d_fpl = dense.get("frames_per_launch") or 1.0
+        launch_bytes = (MODEL_BYTES_PER_PIXEL + FRAME_BYTES_PER_PIXEL * d_fpl) * dense["px_per_launch"]
+        a_dense = launch_bytes / (dense["avg_launch_ms"] * 1e-3) / 1e9
         d_tr = (pmc or {}).get("dense", {}).get("bytes_per_launch")
         da = dense.get("audit") or {}
         d_req = (da.get("sector32_read_B_per_px", 0) + da.get("sector32_write_B_per_px", 0)) * dense["px_per_launch"]
+        if abs(d_fpl - da.get("frames_per_launch", 1.0)) > 1e-6:
+            d_req = 0                    # the audit describes one-frame launches, this leg ran two frames a launch
+        per_frame_equiv = BYTES_PER_PIXEL * d_fpl * dense["px_per_launch"] / (dense["avg_launch_ms"] * 1e-3) / 1e9
         roofline.update(
             leg="4k1 --dense-model, run inside this process: every pixel keeps five live modes and never matches the "
-                "first one, so every lane loads all 104 B/px; stores go out for planes whose bits changed (dense_audit); "
-                "HIP events on the kernel's own stream",
+                "first one, so every lane loads the whole model; stores go out for planes whose bits changed "
+                "(dense_audit); HIP events on the kernel's own stream",
             achieved=a_dense, frac=a_dense / HBM_PEAK_GBPS, frac_dense=a_dense / HBM_PEAK_GBPS,
-            bytes_per_launch=BYTES_PER_PIXEL * dense["px_per_launch"], avg_launch_ms=dense["avg_launch_ms"],
+            frames_per_launch=d_fpl, bytes_per_launch=launch_bytes, avg_launch_ms=dense["avg_launch_ms"],
+            avg_ms_per_frame=dense["avg_launch_ms"] / d_fpl,
+            one_pass_per_frame_equivalent_GBps=per_frame_equiv,
             dense_audit=dense.get("audit"), traffic=d_tr,
             frac_dense_traffic=(d_tr / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if d_tr else None,
             frac_dense_requested=(d_req / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if d_req else None,
-            note="achieved = the contract's ALGORITHMIC 205 B/px / kernel time on the leg built to move them, in the "
-                 "SUSTAINED state (300 steps timed behind 1 200 warm-up steps, ~0.4 s of full load); "
-                 "frac_dense_traffic = the same launch priced at its PMC bytes, frac_dense_requested at the 32-byte "
-                 "sectors the kernel itself counted; *_burst = the first 100 steps of a device that was idle (the "
-                 "state the short PMC child passes -- pmc.dense.avg_duration_us -- and any short run see)")
+            note="achieved = the bytes a launch must move AS EXECUTED -- (202 + 3 x frames_per_launch) B/px: the model in "
+                 "and out once, frames_per_launch frames in; 205 B/px with one frame a launch (SURVEY 8d), 208 B/px for "
+                 "TWO frames with two (--fusion 2, the library's default: the mixture stays in registers between two "
+                 "consecutive frames) -- / kernel time on the leg built to move them, in the SUSTAINED state (300 steps "
+                 "timed behind 1 200 warm-up steps); frac <= 1 by construction.  one_pass_per_frame_equivalent_GBps = "
+                 "205 B/px x frames_per_launch / kernel time: what a kernel that re-reads the model for every frame "
+                 "would have to sustain for the same frame rate -- above the pin rate with two frames a launch, NOT a "
+                 "roofline fraction.  frac_dense_traffic = the launch priced at its PMC bytes, frac_dense_requested at "
+                 "the 32-byte sectors the kernel itself counted; *_burst = the first 100 steps of a device that was idle")
+        if dense.get("one_frame_avg_launch_ms"):
+            t1 = dense["one_frame_avg_launch_ms"]
+            roofline["one_frame_a_launch"] = dict(
+                avg_launch_ms=t1, bytes_per_launch=BYTES_PER_PIXEL * dense["px_per_launch"],
+                achieved=BYTES_PER_PIXEL * dense["px_per_launch"] / (t1 * 1e-3) / 1e9,
+                frac=BYTES_PER_PIXEL * dense["px_per_launch"] / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                note="the same dense leg with oatgpu_set_fusion(1): SURVEY 8d's 205 B/px per launch, sustained state")
         if dense.get("burst_avg_launch_ms"):
             roofline.update(avg_launch_ms_burst=dense["burst_avg_launch_ms"],
-                            frac_burst=BYTES_PER_PIXEL * dense["px_per_launch"] / (dense["burst_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                            frac_burst=launch_bytes / (dense["burst_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
     else:
         roofline.update(leg=None, achieved=None, frac=None, traffic=None,
                         note="dense leg not run (N > 1, --no-dense-leg or host input): no defensible fraction on this line")
     if pmc and pmc.get("benched"):
         b = pmc["benched"]["bytes_per_launch"]
-        benched.update(traffic=b, moved_bytes_per_px=b / px_per_launch,
+        benched.update(traffic=b, moved_bytes_per_px=b / px_per_launch, moved_bytes_per_px_frame=b / px_per_launch / fpl,
                        frac_real=b / (mog_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
-        if aud:
-            benched["waste_ratio"] = benched["moved_bytes_per_px"] / max(benched["useful_bytes_per_px"], 1e-9)
+        if aud:                          # moved per launch / what the launch must ask for at least
+            benched["waste_ratio"] = benched["moved_bytes_per_px"] / max(benched["useful_bytes_per_px_launch_lower_bound"], 1e-9)
     roofline["frac_real"] = benched.get("frac_real")
     roofline["useful_bytes_per_px"] = benched.get("useful_bytes_per_px")
     roofline["waste_ratio"] = benched.get("waste_ratio")
@@ -852,6 +904,7 @@ def main():
                                f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
                    "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
                    "learning_rate": ALPHA, "mog_restore_nmodes": RESTORE, "model_age_frames": handover,
+                   "frames_per_launch": fpl,
                    "parallelism": f"streams sharded, {world} rank(s)"},
         "fps_per_gpu": fps / world,
         "timed_region_ms": elapsed * 1e3,

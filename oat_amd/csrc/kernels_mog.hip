@@ -320,7 +320,13 @@ struct Audit {
 template <int CH, bool AUDIT, bool NTLD, int NF>
 __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
+    // The traffic audit counts one-frame launches only.  (The audited two-frame instantiation was built -- the
+    // counting calls are still in the second-frame code below -- and updated the model wrongly and differently from run
+    // to run at 1080p, tools/state_check.py --audited 6 --fusion 2, while the product instantiations are bit-exact
+    // over the same frames: the same class of fault the audited instantiation showed earlier this round after a
+    // change of a load's type.  Not instantiated; the library launches one frame at a time while an audit is on.)
     static_assert(NF == 1 || !AUDIT, "the traffic audit counts single-frame launches");
+
     Audit<AUDIT> au;
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
     // 79 % VALU-busy at 370 VALU instructions per wave before, profiles/r02_k1_sq_counters_before.md): every plane
@@ -440,6 +446,7 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
         const unsigned fj = valid ? fi : 0u;
         px2 = frame2[fj];
         if (CH == 3) px2 |= (unsigned)frame2[fj + 1] << 8 | (unsigned)frame2[fj + 2] << 16;
+        au.run(valid, CH, false);
     }
     if (!active) return;
 
@@ -521,6 +528,7 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
         // ---- the second frame, on the registers the first one left ----
         const u64 word1 = __ballot(thr);
         if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * nwords + widx] = word1;
+        au.run(a.thr_bits && lane == 0, 8, true);
         b = (int)(px2 & 255u); gg = (int)((px2 >> 8) & 255u); r = (int)(px2 >> 16);
         const int nold2 = nnew;
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
@@ -531,8 +539,10 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
         // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
         const bool need2 = full2 && !full;
 #pragma unroll
-        for (int k = 1; k < kMaxMix; ++k)
+        for (int k = 1; k < kMaxMix; ++k) {
             if (need2 && k < nold2) ld_rec(k, pm.v[k], pm.m[k]);
+            AU_REC(need2 && k < nold2, false);
+        }
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k)
             asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLau
     const u64 word = __ballot(thr);
     u64 *const thr_out = NF == 2 ? a.thr_bits2 : a.thr_bits;
     if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
-    au.run(a.thr_bits && lane == 0, 8, true);
+    au.run(thr_out && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
 #undef LDW
 #undef STW
@@ -631,7 +641,7 @@ static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, i
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
-    if (a.frames2) {                     // two frames a launch (never audited, never fresh: the caller's business)
+    if (a.frames2) {                     // two frames a launch (never fresh, never audited: the caller's business)
         if (a.nt_loads) {
             if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st);
             else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st);

@@ -1063,6 +1063,13 @@ def test_traffic_audit_counts_what_the_kernel_moves(A):
     u = st.traffic_read()
     # + the threshold mask: one 8-byte word per 64 pixels
     assert u["lane_bytes_read"] == 24 * rows * cols and u["lane_bytes_written"] == 20 * rows * cols + rows * cols // 8
+    # an audit counts one-frame launches: the pipelined path does not pair frames while it is on
+    st.traffic_audit(True)
+    st.enqueue([still]); st.enqueue([still])
+    st.collect(); st.collect()
+    u = st.traffic_read()
+    assert u["launches"] == 2 and u["pixels"] == 2 * rows * cols
+    assert u["lane_bytes_read"] == 2 * 24 * rows * cols
 
 
 def test_mask_filter_and_bsub_background_entry_points(A):

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False, log=print):
+def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False, log=print, fusion=None):
     import oat_amd
     import oracle_lib as O
     from oat_amd.synth import SyntheticStream, disc_hsv_window
@@ -36,6 +36,8 @@ def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False,
         fr = [[st[s].frame(9 * t, with_discs=t > 0) for s in range(streams)] for t in range(pool)]
     hp = oat_amd.HotPath(rows, cols, n_streams=streams, adaptation_coeff=alpha, erode=3, dilate=7,
                          area=(20.0, 1e5), ring_depth=4, **disc_hsv_window())
+    if fusion:
+        hp.set_fusion(fusion)
     got = []
     t0 = time.perf_counter()
     for t in range(frames):
@@ -49,8 +51,11 @@ def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False,
     # it must leave the model exactly as the product kernel would
     if audited:
         hp.traffic_audit(True)
-        for t in range(frames, frames + audited):
+        for t in range(frames, frames + audited):           # same ring pattern: the audited launches take two frames too
             hp.enqueue(fr[t % pool])
+            if hp.outstanding() >= 4:
+                got.append(hp.collect())
+        while hp.outstanding():
             got.append(hp.collect())
         hp.traffic_read()
         hp.traffic_audit(False)
@@ -58,6 +63,7 @@ def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False,
     p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0,
                      max_area=1e5)
     bad = 0
+    bad_at = []
     for s in range(streams):
         orc = O.Mog2(rows, cols, 3)
         for t in range(frames):
@@ -65,13 +71,14 @@ def run(rows, cols, frames, pool, alpha=0.01, streams=1, audited=6, dense=False,
             g = got[t][s]
             if g.position_valid != w["valid"] or (w["valid"] and (g.a00, g.a10, g.a01) != (w["a00"], w["a10"], w["a01"])):
                 bad += 1
+                bad_at.append(t)
         nm_g, w_g, v_g, m_g, _ = hp.mog_state(s)
         nm_o, w_o, v_o, m_o = orc.state()
         live = np.arange(w_o.shape[1])[None, :] < nm_o[:, None]
         d = dict(count=int((nm_g != nm_o).sum()), weight=int((w_g[live] != w_o[live]).sum()),
                  variance=int((v_g[live] != v_o[live]).sum()), mean=int((m_g[live] != m_o[live]).sum()))
         log(f"stream {s}: {frames} frames {cols}x{rows}: position mismatches {bad}, model differences {d} "
-            f"(of {int(live.sum())} live modes); GPU {t_gpu:.2f} s")
+            f"(of {int(live.sum())} live modes); GPU {t_gpu:.2f} s" + (f"; positions differ at frames {bad_at[:12]}" if bad_at else ""))
         bad += sum(d.values())
     hp.close()
     return bad
@@ -86,5 +93,6 @@ if __name__ == "__main__":
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--audited", type=int, default=6)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--fusion", type=int, default=0, help="oatgpu_set_fusion (0 = the library's default)")
     a = ap.parse_args()
-    sys.exit(1 if run(a.rows, a.cols, a.frames, a.pool, streams=a.streams, audited=a.audited, dense=a.dense) else 0)
+    sys.exit(1 if run(a.rows, a.cols, a.frames, a.pool, streams=a.streams, audited=a.audited, dense=a.dense, fusion=a.fusion or None) else 0)
