@@ -45,6 +45,21 @@ template <int CH>
 __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // exchange modes i and i-1
 {
     dvm |= (3u << (i - 1));
+    // v_swap_b32 exchanges two VGPRs in one instruction (hipcc writes three moves for a swap through a temporary:
+    // 15 instead of 5 vector instructions per exchanged mode -- the kernel is VALU-bound with two frames a launch,
+    // and on a dense model every bubbling loop runs in every wave)
+    // Measured (gpurun_out/ab_swap.txt, ab_nt.txt): everyday 4K model 130.9 -> 127.0 us per two-frame launch, 16 x 1080p
+    // 523 -> 507 us; dense model unchanged once its instantiation is out of scratch.  BGR only: the GREY two-frame
+    // instantiation went INTO scratch with it (the asm operands pin registers).
+#ifndef OATGPU_NO_VSWAP          // (make variant NAME=noswap DEFS=-DOATGPU_NO_VSWAP: the A/B build)
+    if (CH == 3) {
+        asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
+        asm volatile("v_swap_b32 %0, %1" : "+v"(s.v[i]), "+v"(s.v[i - 1]));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) asm volatile("v_swap_b32 %0, %1" : "+v"(s.m[i][c]), "+v"(s.m[i - 1][c]));
+        return;
+    }
+#endif
     float t;
     t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
     t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
@@ -317,8 +332,17 @@ struct Audit {
 // frame needs beyond the first's registers: a lane that matched mode 0 as background in frame 1 never loaded the
 // records of its later slots; if it is a "full" lane in frame 2 it loads them then (they are untouched: such a lane
 // changes slot 0 only).  Weights are always current in registers (a slot not loaded was dead = 0 and stays 0).
+// Waves per SIMD the two-frame instantiations are compiled for.  The streaming-load one (dense models) needs 72
+// registers to stay out of scratch: at 8 waves (64 registers, 20-40 bytes of scratch a lane) the dense 4K launch took
+// 343-351 us, at 7 waves 285-293 us, at 6 waves 303-308 us (gpurun_out/ab_nt.txt).
+#ifndef OATGPU_NT2_WAVES
+#define OATGPU_NT2_WAVES 7
+#endif
+#ifndef OATGPU_F2_WAVES
+#define OATGPU_F2_WAVES 8
+#endif
 template <int CH, bool AUDIT, bool NTLD, int NF>
-__global__ __launch_bounds__(256, AUDIT ? 4 : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, AUDIT ? 4 : (NF == 2 && NTLD) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     // The traffic audit counts one-frame launches only.  (The audited two-frame instantiation was built -- the
     // counting calls are still in the second-frame code below -- and updated the model wrongly and differently from run
