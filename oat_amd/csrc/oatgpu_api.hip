@@ -1072,6 +1072,15 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     }
     c->launched_total += (unsigned long long)nj;
 
+    // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
+    // a second marker packet between two K1s on stream A)
+    hipEvent_t k1_done = nullptr;
+    if (!(c->expt & 1)) {
+        const int nbe0 = (j[0].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
+        k1_done = c->ev_k1[j[0].slot % nbe0];
+        HIPCHK(c, hipEventRecord(k1_done, A));
+    }
+
     for (int i = 0; i < nj; ++i) {
         const int slot = j[i].slot;
         // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
@@ -1086,10 +1095,8 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
             continue;
         }
-        HIPCHK(c, hipEventRecord(c->ev_k1[q], A));
-
         // Stream B[q]: morphology + blob analysis of this frame.
-        HIPCHK(c, hipStreamWaitEvent(B, c->ev_k1[q], 0));
+        HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
         if (c->use_graph && !c->back_graph[slot]) {
             c->back_graph[slot] = capture_back_half(c, slot, B);
             if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
