@@ -86,7 +86,10 @@ class FrameScatterPipe:
             local = pipe.take(t)                               # ... step t is taken and computed
             compute(local)
 
-    post(t) uses buffer slot t % depth, so take(t)'s tensor stays valid until post(t + depth).  Backend "nccl"
+    post(t) uses buffer slot t % depth, so take(t)'s tensor stays valid until post(t + depth).  A frame handed to
+    HotPath.enqueue_dev must stay untouched until its result was collected (the library may launch its kernels only
+    with the NEXT frame: two frames a launch, oatgpu_set_fusion): collect step t before post(t + depth), or make
+    depth the ring depth + 1.  Backend "nccl"
     (= RCCL) on the GPU box; the tests drive the same code over gloo.  Unmeasured on multi-GPU hardware so far
     (the builder has one GPU at a time): the driver's SCALE run uses per-rank ingest, not this path."""
 
