@@ -726,6 +726,27 @@ def main():
             except Exception as e:
                 log(f"extra workload {name} failed:", e)
 
+    # ---- the benched workload once more with ONE frame a launch (oatgpu_set_fusion(1)): the A/B of the line ----
+    one_frame = None
+    if solo and FUSION == 2 and not args.no_extra and args.input == "device" and not args.dense_model:
+        try:
+            l1 = Leg(args.workload, local_rank, rank, pool=args.pool)
+            l1.hp.set_fusion(1)
+            k1n = min(max(K, 200), 1000)
+            o_el, _, o_prof, _, _, _ = timed_run(l1, k1n, max(W, 50), lambda: (l1.hp.synchronize(), torch.cuda.synchronize()), 8,
+                                                 age_frames=AGE, export=False, spin=0.0 if args.no_spin_up else 0.2,
+                                                 spin_args=(args.workload, local_rank, rank))
+            one_frame = dict(value=ns * k1n / o_el, unit="frames/s", steps=k1n, ms_per_step=o_el / k1n * 1e3,
+                             k_mog_fused_ms=k1_ms(o_prof)[0], frames_per_launch=o_prof["mog_frames"] / max(o_prof["steps"], 1),
+                             note="same workload, same ageing, oatgpu_set_fusion(1): what the pipelined path does when "
+                                  "every frame is collected before the next is enqueued; not gated in this run (the "
+                                  "-m gpu tests compare both forms with the oracle and with each other)")
+            l1.close()
+            del l1
+            torch.cuda.empty_cache()
+        except Exception as e:
+            log("one-frame-a-launch leg failed:", e)
+
     total_streams = ns * world
     fps = total_streams * K / elapsed
     px_per_launch = rows * cols * ns
@@ -928,6 +949,7 @@ def main():
 
     if solo and not args.no_extra and args.input == "device" and not args.dense_model:
         line["extra_workloads"] = extra
+        line["one_frame_a_launch"] = one_frame
 
     if not args.no_cpu_baseline and solo:          # rank 0 at N = 1 only (the other ranks would idle meanwhile)
         line["cpu_baseline"] = cpu_baseline(args.workload, pool_host0)
