@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_profile.mog_frames */
+#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames */
 
 enum {
     OATGPU_OK = 0,
@@ -180,6 +180,13 @@ int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_l
  * The single-stage oatgpu_detect_* calls are never filtered. */
 int oatgpu_set_kalman(oatgpu_ctx *ctx, int32_t enable, double dt, double timeout, double sigma_accel,
                       double sigma_noise);
+
+/* `posifilt homography` on the batch (src/positionfilter/HomographyTransform2D.cpp:62-107) behind the detector and,
+ * when it is on, the position filter: every result of the fused track calls goes through cv::perspectiveTransform with
+ * the row-major 3x3 matrix h9 (--homography [h11,h12,...,h33], :44-58) -- position where valid, velocity where valid
+ * with the matrix' offsets zeroed (:79-89).  raw_x / raw_y keep the detector's pixels.  The caller marks the
+ * Position2D it publishes as WORLD units with this matrix (Position2D::setCoordSystem, :102).  enable = 0: off. */
+int oatgpu_set_homography(oatgpu_ctx *ctx, int32_t enable, const double *h9);
 
 /* `framefilt mask` fused in front of mog (src/framefilter/FrameMasker.cpp:71-75:
  * frame.setTo(0, roi_mask == 0)): roi_mask is rows*cols bytes, nonzero = keep; NULL removes the

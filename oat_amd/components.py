@@ -346,6 +346,15 @@ class HotPath(_Context):
         reference's).  (Re)starts every stream's filter."""
         self._chk(self.lib.oatgpu_set_kalman(self.ctx, int(bool(enable)), dt, timeout, sigma_accel, sigma_noise))
 
+    def set_homography(self, h=None):
+        """`posifilt homography` behind the detector / the position filter (HomographyTransform2D.cpp): h = nine numbers,
+        row-major [h11, h12, ..., h33]; None turns it off."""
+        if h is None:
+            self._chk(self.lib.oatgpu_set_homography(self.ctx, 0, None))
+        else:
+            a = (C.c_double * 9)(*[float(v) for v in np.asarray(h, np.float64).reshape(9)])
+            self._chk(self.lib.oatgpu_set_homography(self.ctx, 1, a))
+
     def set_stream(self, hip_stream):
         self._chk(self.lib.oatgpu_set_stream(self.ctx, C.c_void_p(hip_stream)))
 

@@ -86,6 +86,10 @@ struct oatgpu_ctx {
     // somebody needs the frame's result or the model (collect / ready of that very frame, every synchronous entry
     // point, destroy), then for the one frame alone.  Results, their order and the model are those of one launch a frame.
     struct FrameJob { const void *frames = nullptr; double lr = 0.0; hipEvent_t ready = nullptr; int slot = 0; };
+    // `posifilt homography` behind the detector / the position filter (oatgpu_set_homography): applied where the
+    // centroid is finished, on the host, in the reference's double arithmetic
+    bool homo_on = false;
+    double homo[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     int fuse = 2;
     bool pend_valid = false;
     FrameJob pend;
@@ -653,6 +657,42 @@ extern "C" int oatgpu_set_kalman(oatgpu_ctx *c, int32_t enable, double dt, doubl
     return OATGPU_OK;
 }
 
+// HomographyTransform2D::filter (HomographyTransform2D.cpp:62-107) on one result: cv::perspectiveTransform of a
+// CV_64FC2 point (OpenCV 3.1.0 core/matmul.cpp perspectiveTransform_<double>: w = x m6 + y m7 + m8; |w| > FLT_EPSILON ->
+// multiply by 1/w, else (0, 0)); the velocity through the same matrix with its offsets zeroed (:79-89).
+static void perspective_point(const double *m, double &px, double &py)
+{
+    const double x = px, y = py;
+    double w = x * m[6] + y * m[7] + m[8];
+    if (fabs(w) > (double)FLT_EPSILON) {
+        w = 1. / w;
+        px = (x * m[0] + y * m[1] + m[2]) * w;
+        py = (x * m[3] + y * m[4] + m[5]) * w;
+    } else {
+        px = py = 0;
+    }
+}
+static void apply_homography(const oatgpu_ctx *c, oatgpu_position *o)
+{
+    if (o->valid) perspective_point(c->homo, o->x, o->y);
+    if (o->velocity_valid) {
+        double v[9];
+        for (int i = 0; i < 9; ++i) v[i] = c->homo[i];
+        v[2] = 0.0; v[5] = 0.0;
+        perspective_point(v, o->vx, o->vy);
+    }
+}
+
+extern "C" int oatgpu_set_homography(oatgpu_ctx *c, int32_t enable, const double *h9)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (enable && !h9) return fail(c, OATGPU_E_INVALID, "null homography");
+    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "set_homography while enqueued results are outstanding");
+    c->homo_on = enable != 0;
+    if (enable) for (int i = 0; i < 9; ++i) c->homo[i] = h9[i];
+    return OATGPU_OK;
+}
+
 extern "C" int oatgpu_set_roi_mask(oatgpu_ctx *c, int32_t s, const uint8_t *roi_mask)
 {
     int rc = check_stream_ix(c, s);
@@ -1204,6 +1244,7 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     for (int s = 0; s < c->cfg.n_streams; ++s) {
         to_position(r[s], &out[s]);
         if (c->slot_filtered[slot]) apply_kalman(r[s], &out[s]);
+        if (c->homo_on) apply_homography(c, &out[s]);
     }
     c->col_total++;
     c->ring_count--;

@@ -403,6 +403,17 @@ struct Options {
         if (sscanf(s.c_str(), " [ %lf , %lf ]", &a, &b) != 2) throw std::runtime_error("'" + k + "' must be a 2-element array, e.g. [0,256]");
         return true;
     }
+    // "[h11,...,h33]" -> 9 numbers (getArray<double, 9>, HomographyTransform2D.cpp:48-58)
+    bool arr9(const std::string &k, double *h) const
+    {
+        if (!has(k)) return false;
+        const std::string &s = kv.at(k);
+        char tail = 0;
+        if (sscanf(s.c_str(), " [ %lf , %lf , %lf , %lf , %lf , %lf , %lf , %lf , %lf %c", h, h + 1, h + 2, h + 3, h + 4, h + 5,
+                   h + 6, h + 7, h + 8, &tail) != 10 || tail != ']')
+            throw std::runtime_error("'" + k + "' must be a 9-element array, [h11,h12,...,h33]");
+        return true;
+    }
 };
 
 }  // namespace oat

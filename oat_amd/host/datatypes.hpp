@@ -120,6 +120,12 @@ public:
 
     void set_sample(const Sample &s) { sample_ = s; }
     const Sample &sample() const { return sample_; }
+    // Position2D.h:138-142
+    void setCoordSystem(DistanceUnit value, const double homography[9])
+    {
+        unit_of_length_ = value;
+        for (int i = 0; i < 9; ++i) homography_[i] = homography[i];
+    }
     const char *label() const { return label_; }
 
     static constexpr size_t REGION_LEN{10};

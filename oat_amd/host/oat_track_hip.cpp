@@ -65,6 +65,8 @@ public:
     std::string model_file_;        // --model-file: resume the MOG2 model(s) from / checkpoint to this file
     std::string mask_file_;         // --mask: `framefilt mask` fused in front of mog (FrameMasker.cpp:45-75)
     bool grey_{false};              // --thresh: GREY frames, mog -> posidet thresh
+    bool homography_on_{false};     // --homography: `posifilt homography` behind the detector / the position filter
+    double homography_[9]{1, 0, 0, 0, 1, 0, 0, 0, 1};
     ~BatchedTracker() override
     {
         if (!model_file_.empty() && gpu_.ctx)
@@ -101,6 +103,7 @@ protected:
             for (int s = 0; s < n_; ++s) gpu_.check(oatgpu_set_roi_mask(gpu_.ctx, s, m.px.data()));
         }
         if (kalman_) gpu_.check(oatgpu_set_kalman(gpu_.ctx, 1, dt_, timeout_, sig_accel_, sig_noise_));
+        if (homography_on_) gpu_.check(oatgpu_set_homography(gpu_.ctx, 1, homography_));
         for (int s = 0; s < n_; ++s) {
             position_sinks_[s].bind(sink_addresses_[s], sink_addresses_[s]);
             shared_positions_.push_back(position_sinks_[s].retrieve());
@@ -128,6 +131,7 @@ protected:
             } else if (r.valid) {                                    // DetectorFunc.cpp:46,58-60: x/y only when found
                 pos.position.x = r.x; pos.position.y = r.y;
             }
+            if (homography_on_) pos.setCoordSystem(DistanceUnit::WORLD, homography_);   // HomographyTransform2D.cpp:102
             position_sinks_[s].wait();
             *shared_positions_[s] = pos;
             position_sinks_[s].post();
@@ -194,12 +198,13 @@ int main(int argc, char **argv)
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
                          "       [--gpu-index N] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
                          "       [--thresh [lo,hi]]   GREY SOURCEs: framefilt mog -> posidet thresh instead of the HSV chain\n"
+                         "       [--homography [h11,h12,...,h33]]   posifilt homography fused in (positions in world units)\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
                          "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh"}, {"kalman"});
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography"}, {"kalman"});
         auto t = std::make_unique<BatchedTracker>(split_list(o.positional[0]), split_list(o.positional[1]));
         t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
         double a, b;
@@ -219,6 +224,7 @@ int main(int argc, char **argv)
         if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
         if (o.has("mask")) t->mask_file_ = o.kv["mask"];
         t->kalman_ = o.has("kalman");
+        t->homography_on_ = o.arr9("homography", t->homography_);
         t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)
         t->timeout_ = o.num("timeout", 0.0, 0, 1e18);
         t->sig_accel_ = o.num("sigma-accel", 5.0, 0, 1e18);

@@ -162,3 +162,38 @@ void oat_kalman_filter(oat_kalman *k, int position_valid, double x, double y, oa
     out->position_valid = k->found;
     out->velocity_valid = k->found;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * posifilt homography (HomographyTransform2D.cpp:62-107) -- ORACLE, test infrastructure.
+ * cv::perspectiveTransform on one CV_64FC2 point with a 3x3 double matrix, OpenCV 3.1.0 core/matmul.cpp
+ * perspectiveTransform_<double>:  w = x*m[6] + y*m[7] + m[8];  if (fabs(w) > FLT_EPSILON) { w = 1./w;
+ * x' = (x*m[0] + y*m[1] + m[2])*w;  y' = (x*m[3] + y*m[4] + m[5])*w; } else x' = y' = 0.
+ * The velocity goes through the same matrix with its offsets m[2], m[5] set to 0 (:79-89).  (Headings too,
+ * followed by cv::normalize -- no detector on this path produces one.)  The position's unit becomes WORLD. */
+#include <float.h>
+#include <math.h>
+static void perspective_point(const double *m, double *px, double *py)
+{
+    const double x = *px, y = *py;
+    double w = x * m[6] + y * m[7] + m[8];
+    if (fabs(w) > FLT_EPSILON) {
+        w = 1. / w;
+        *px = (x * m[0] + y * m[1] + m[2]) * w;
+        *py = (x * m[3] + y * m[4] + m[5]) * w;
+    } else
+        *px = *py = 0;
+}
+
+void oat_homography_filter(const double h[9], int position_valid, double *x, double *y, int velocity_valid,
+                           double *vx, double *vy)
+{
+    if (position_valid) perspective_point(h, x, y);
+    if (velocity_valid) {
+        double v[9];
+        for (int i = 0; i < 9; i++) v[i] = h[i];
+        v[2] = 0.0;
+        v[5] = 0.0;
+        perspective_point(v, vx, vy);
+    }
+}

@@ -237,6 +237,11 @@ void oat_kalman_destroy(oat_kalman *k);
 /* KalmanFilter2D::filter(position): in = posidet's (position_valid, position) */
 void oat_kalman_filter(oat_kalman *k, int position_valid, double x, double y, oat_kalman_out *out);
 
+/* posifilt homography (HomographyTransform2D.cpp:62-107): cv::perspectiveTransform of the position (and, with its
+ * offsets zeroed, of the velocity) through the row-major 3x3 matrix h; in place. */
+void oat_homography_filter(const double h[9], int position_valid, double *x, double *y, int velocity_valid,
+                           double *vx, double *vy);
+
 #ifdef __cplusplus
 }
 #endif

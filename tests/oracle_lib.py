@@ -359,6 +359,18 @@ def thresh_filter(frame, i_min, i_max):
     return f
 
 
+def homography(h, valid, x, y, velocity_valid=False, vx=0.0, vy=0.0):
+    """posifilt homography on one position (oat_homography_filter); returns (x, y, vx, vy)."""
+    H = (C.c_double * 9)(*[float(v) for v in np.asarray(h, np.float64).reshape(9)])
+    cx, cy, cvx, cvy = C.c_double(x), C.c_double(y), C.c_double(vx), C.c_double(vy)
+    lib.oat_homography_filter.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.oat_homography_filter.restype = None
+    lib.oat_homography_filter(H, int(bool(valid)), C.byref(cx), C.byref(cy), int(bool(velocity_valid)),
+                              C.byref(cvx), C.byref(cvy))
+    return cx.value, cy.value, cvx.value, cvy.value
+
+
 class KalmanParams(C.Structure):
     _fields_ = [("dt", C.c_double), ("timeout", C.c_double), ("sigma_accel", C.c_double),
                 ("sigma_noise", C.c_double)]

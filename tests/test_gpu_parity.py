@@ -1289,3 +1289,50 @@ def test_two_frames_a_launch_with_changing_rates_and_early_collects(A):
             _same_detection(got[t][s], want, (t, s))
     for s in range(n):
         _same_state(hp.mog_state(s), orcs[s].state(), s)
+
+
+def test_homography_behind_detector_and_kalman(A):
+    """oatgpu_set_homography (`posifilt homography`, HomographyTransform2D.cpp:62-107) on the batch: behind the detector
+    alone and behind the position filter (velocity through the matrix without its offsets); raw_x / raw_y keep pixels."""
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 120, 200, 2
+    H = [0.02, 0.001, -1.5, -0.002, 0.025, 0.75, 1e-4, -2e-4, 1.0]
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    streams = [SyntheticStream(rows, cols, 20 + s, n_discs=1, radius=10) for s in range(n)]
+    frames = [[st.frame(t, with_discs=t > 0) for st in streams] for t in range(30)]
+    for kalman in (False, True):
+        hp = A.HotPath(rows, cols, n_streams=n, adaptation_coeff=0.01, erode=3, dilate=7, area=(20.0, 1e5), ring_depth=4, **win)
+        if kalman:
+            hp.set_kalman(True, dt=0.02, timeout=0.1, sigma_accel=5.0, sigma_noise=1.0)
+        hp.set_homography(H)
+        orcs = [O.Mog2(rows, cols, 3) for _ in range(n)]
+        kfs = [O.Kalman(dt=0.02, timeout=0.1, sigma_accel=5.0, sigma_noise=1.0) for _ in range(n)] if kalman else None
+        got = []
+        for f in frames:
+            hp.enqueue(f)
+            if hp.outstanding() >= 4:
+                got.append(hp.collect())
+        while hp.outstanding():
+            got.append(hp.collect())
+        hits = 0
+        for t, f in enumerate(frames):
+            for s in range(n):
+                want, _ = O.chain_step(orcs[s], f[s], 0.01, p)
+                g = got[t][s]
+                if kalman:
+                    k = kfs[s].filter(want["valid"], want["x"], want["y"])
+                    x, y, vx, vy = O.homography(H, k["position_valid"], k["x"], k["y"], k["velocity_valid"], k["vx"], k["vy"])
+                    assert g.position_valid == k["position_valid"] and g.velocity_valid == k["velocity_valid"], (t, s)
+                    if k["position_valid"]:
+                        assert (g.x, g.y, g.vx, g.vy) == (x, y, vx, vy), (t, s)
+                        hits += 1
+                else:
+                    assert g.position_valid == want["valid"], (t, s)
+                    if want["valid"]:
+                        x, y, _, _ = O.homography(H, True, want["x"], want["y"])
+                        assert (g.x, g.y) == (x, y) and (g.raw_x, g.raw_y) == (want["x"], want["y"]), (t, s, g, want)
+                        hits += 1
+        assert hits >= 40
+        hp.set_homography(None)
+        hp.close()

@@ -218,6 +218,31 @@ def test_col_refuses_what_the_reference_refuses(host_bins):
     assert r.returncode == 255 and "Invalid color." in r.stderr
 
 
+@pytest.mark.gpu
+def test_fused_tracker_with_homography_matches_oracle(host_bins, tmp_path):
+    """oat-track-hip --homography = ... -> posidet hsv -> posifilt homography in one process: positions in WORLD units
+    (JSON "unit": 1, Position2D.h:170-233) equal cv::perspectiveTransform of the oracle chain's pixels."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 16
+    H = [0.01, 0.0, -1.6, 0.0, -0.01, 1.2, 0.0, 1e-4, 1.0]
+    st = SyntheticStream(rows, cols, 8, n_discs=1, radius=12)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(n)]
+    got = _run_pipeline(host_bins, tmp_path, frames, True, ["--homography", "[" + ",".join(repr(v) for v in H) + "]"])
+    assert len(got) == n
+    orc = O.Mog2(rows, cols, 3)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    hits = 0
+    for t, (f, g) in enumerate(zip(frames, got)):
+        want, _ = O.chain_step(orc, f, 0.01, p)
+        assert g["unit"] == 1 and g["pos_ok"] == want["valid"], t
+        if want["valid"]:
+            x, y, _, _ = O.homography(H, True, want["x"], want["y"])
+            assert abs(g["pos_xy"][0] - x) < 1e-5 and abs(g["pos_xy"][1] - y) < 1e-5, t     # JSON carries 5 decimals
+            hits += 1
+    assert hits >= n - 3
+
+
 def test_config_file_errors_are_the_references(host_bins, tmp_path):
     """-c FILE KEY (TOMLSanitize.h:73-118): bad pair, missing table, unknown key -> error exit, the
     reference's messages; none of this needs a GPU (options are parsed before any device work)."""

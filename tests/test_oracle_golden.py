@@ -319,3 +319,22 @@ def test_cvt_color_table_is_the_references():
         if code > 0:
             ref = {(C3, H): O.bgr2hsv, (H, C3): O.hsv2bgr}.get((src, dst), O.bgr2grey if src == C3 else O.grey2bgr)(f)
             assert out.shape == ref.shape and (out == ref).all()
+
+
+def test_homography_filter_known_answers():
+    """posifilt homography (HomographyTransform2D.cpp:62-107) = cv::perspectiveTransform on one point; hand-computed:
+    identity; scale + offset (the velocity loses the offset, :79-89); a projective row; |w| <= FLT_EPSILON -> (0, 0);
+    invalid parts are left alone."""
+    assert O.homography(np.eye(3), True, 12.5, -3.0, True, 1.0, 2.0) == (12.5, -3.0, 1.0, 2.0)
+    h = [2.0, 0.0, 10.0, 0.0, 0.5, -4.0, 0.0, 0.0, 1.0]
+    assert O.homography(h, True, 3.0, 8.0, True, 1.0, 2.0) == (16.0, 0.0, 2.0, 1.0)
+    # w = 0.01 x + 1: x = 100 -> w = 2; (x', y') = ((x + 2y) / 2, y / 2)
+    h = [1.0, 2.0, 0.0, 0.0, 1.0, 0.0, 0.01, 0.0, 1.0]
+    x, y, vx, vy = O.homography(h, True, 100.0, 10.0, False, 7.0, 7.0)
+    assert (x, y, vx, vy) == ((100.0 + 20.0) * (1.0 / 2.0), 10.0 * (1.0 / 2.0), 7.0, 7.0)
+    # the reference multiplies by the reciprocal of w: 1/3 rounds, so x * (1/3) is not x / 3 for every x
+    h = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 3.0]
+    assert O.homography(h, True, 5.0, 7.0)[:2] == (5.0 * (1.0 / 3.0), 7.0 * (1.0 / 3.0))
+    h = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1e-8]          # |w| <= FLT_EPSILON
+    assert O.homography(h, True, 5.0, 7.0)[:2] == (0.0, 0.0)
+    assert O.homography(h, False, 5.0, 7.0)[:2] == (5.0, 7.0)
