@@ -66,6 +66,8 @@ struct oatgpu_ctx {
     bool lds_spec = true;
     int lds_streak = 0;
     std::vector<char> slot_spec, slot_q;      // per ring slot: launched speculatively? which scratch set / B stream?
+    std::vector<int> slot_ev;                 // per ring slot: the slot whose ring event covers this slot's result (itself,
+                                              // or the second frame of its launch when both back halves share a B stream)
     int ring_slots = 0;                               // internal ring size (= ring_depth); one threshold-bit buffer per slot
     bool serial = false;
     hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
@@ -448,6 +450,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         c->slot_filtered.assign(c->ring_slots, 0);
         c->slot_spec.assign(c->ring_slots + 1, 0);
         c->slot_q.assign(c->ring_slots + 1, 0);
+        c->slot_ev.resize(c->ring_slots);
+        for (int i = 0; i < c->ring_slots; ++i) c->slot_ev[i] = i;
         for (auto &e : c->ring_ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming | ((c->expt & 8) ? hipEventDisableSystemFence : 0)) != hipSuccess) ok = false;
     }
@@ -1121,22 +1125,28 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         HIPCHK(c, hipEventRecord(k1_done, A));
     }
 
+    // Small frames are bound by the host's launch calls: the two back halves of a two-frame step
+    // then go down ONE B stream behind one wait, and one ring event -- recorded behind the second -- covers both
+    // results (8 runtime calls a step instead of 10): 3 x 320x240 78 k -> 108 k fps.  From about a megapixel a step on
+    // the back halves are long enough to want a stream each (one 1080p stream: 45.8 k fps apart, 38.9 k fps together).
+    const bool share_b = nj == 2 && (size_t)n * (size_t)c->g.P <= ((size_t)1 << 20) && !(c->expt & 1) && !c->use_graph && !c->serial;
     for (int i = 0; i < nj; ++i) {
         const int slot = j[i].slot;
         // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
         // fewer then: the copy stream sits on the last B stream's hardware queue (see acquire_streams)
         const int nbe = (j[i].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
-        const int q = slot % nbe;
+        const int q = (share_b ? j[0].slot : slot) % nbe;
         const int k = slot;                              // threshold-bit buffer of this frame
         hipStream_t B = c->serial ? c->stream : c->stream_b[q];
         c->b_used[q] = true;
         ProfStep *pb = i == 0 ? ps : nullptr;           // the back half of the step's first frame is the sampled one
         if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
+            c->slot_ev[slot] = slot;
             HIPCHK(c, hipEventRecord(c->ring_ev[slot], A));
             continue;
         }
         // Stream B[q]: morphology + blob analysis of this frame.
-        HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
+        if (!(share_b && i == 1)) HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
         if (c->use_graph && !c->back_graph[slot]) {
             c->back_graph[slot] = capture_back_half(c, slot, B);
             if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
@@ -1164,7 +1174,9 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         }
         c->slot_filtered[slot] = c->kal_on;
         if (pb) HIPCHK(c, hipEventRecord(pb->e[4], B));
-        HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
+        c->slot_ev[slot] = slot;
+        if (share_b && i == 0) c->slot_ev[slot] = j[1].slot;       // the second frame's event, recorded below, covers it
+        else HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
         c->last_q = k;
     }
     return OATGPU_OK;
@@ -1215,7 +1227,7 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
         const int frc = flush_pending(c);
         if (frc) return frc;
     }
-    HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+    HIPCHK(c, hipEventSynchronize(c->ring_ev[c->slot_ev[slot]]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
     {   // speculation bookkeeping (see lds_spec)
         constexpr int kSpecAfter = 16;
@@ -1268,7 +1280,7 @@ extern "C" int oatgpu_track_ready(oatgpu_ctx *c)
         const int frc = flush_pending(c);
         if (frc) return frc;
     }
-    const hipError_t e = hipEventQuery(c->ring_ev[slot]);
+    const hipError_t e = hipEventQuery(c->ring_ev[c->slot_ev[slot]]);
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) return 0;
     return fail(c, OATGPU_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
