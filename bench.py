@@ -759,17 +759,18 @@ def main():
                    note="a launch takes frames_per_launch consecutive frames of every stream on ONE pass over the model "
                         "(oatgpu_set_fusion); avg_launch_ms, traffic and moved_bytes_per_px are per LAUNCH, "
                         "moved_bytes_per_px_frame = that / frames_per_launch; useful_* / requested_* are the kernel's own "
-                        "audit of ONE-frame launches")
+                        "audit of its launches (audit_frames_per_launch frames each)")
     if aud:
-        # the audit counts ONE-frame launches (the library does not pair frames while it is on): what one pass over the
-        # model for one frame asks for.  A two-frame launch asks for at least that + the second frame's 3 B/px and
-        # threshold words (a lower bound: lanes that only become "full" in the second frame load their records late,
-        # and more planes end up changed).
+        # the audit counts the launches as the library makes them (two frames a launch on the pipelined path): per pixel
+        # and LAUNCH.  Where its launches and the timed ones differ in frames (GREY contexts audit one frame at a time)
+        # the second frame's 3 B/px and threshold words are added as a lower bound.
         u1 = aud["useful_read_B_per_px"] + aud["useful_write_B_per_px"]
-        benched.update(useful_bytes_per_px=u1,
+        a_fpl = aud["frames_per_launch"]
+        benched.update(useful_bytes_per_px=u1, audit_frames_per_launch=a_fpl,
+                       useful_bytes_per_px_frame=u1 / max(a_fpl, 1e-9),
                        requested_sector32_bytes_per_px=aud["sector32_read_B_per_px"] + aud["sector32_write_B_per_px"],
                        requested_sector64_bytes_per_px=aud["sector64_read_B_per_px"] + aud["sector64_write_B_per_px"],
-                       useful_bytes_per_px_launch_lower_bound=u1 + (fpl - 1.0) * (FRAME_BYTES_PER_PIXEL + 0.125),
+                       useful_bytes_per_px_launch_lower_bound=u1 + max(fpl - a_fpl, 0.0) * (FRAME_BYTES_PER_PIXEL + 0.125),
                        audit=aud, mode_histogram=hist)
     # ---- the leg where the algorithmic bytes really move: 4K, all five modes live on every pixel ----
     dense = None

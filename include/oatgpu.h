@@ -162,7 +162,7 @@ int oatgpu_synchronize(oatgpu_ctx *ctx);
  * second frame.  Results, their order, the threshold images and the model are bit-identical either way
  * (FrameFilter.cpp:59-98 / PositionDetector.cpp:58-99: one token out per token in, in order).
  * The caller's frame of oatgpu_track_enqueue_dev must stay valid until its result was collected (as before).
- * While a traffic audit is on (oatgpu_traffic_audit) every launch takes one frame. */
+ * While a traffic audit is on (oatgpu_traffic_audit) GREY contexts launch one frame at a time. */
 int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
 /* Re-configure the detector between frames (what the reference's tuning GUI

@@ -335,6 +335,9 @@ struct Audit {
 // Waves per SIMD the two-frame instantiations are compiled for.  The streaming-load one (dense models) needs 72
 // registers to stay out of scratch: at 8 waves (64 registers, 20-40 bytes of scratch a lane) the dense 4K launch took
 // 343-351 us, at 7 waves 285-293 us, at 6 waves 303-308 us (gpurun_out/ab_nt.txt).
+#ifndef OATGPU_AUDIT_WAVES
+#define OATGPU_AUDIT_WAVES 4
+#endif
 #ifndef OATGPU_NT2_WAVES
 #define OATGPU_NT2_WAVES 7
 #endif
@@ -342,14 +345,16 @@ struct Audit {
 #define OATGPU_F2_WAVES 8
 #endif
 template <int CH, bool AUDIT, bool NTLD, int NF>
-__global__ __launch_bounds__(256, AUDIT ? 4 : (NF == 2 && NTLD) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && NTLD) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
-    // The traffic audit counts one-frame launches only.  (The audited two-frame instantiation was built -- the
-    // counting calls are still in the second-frame code below -- and updated the model wrongly and differently from run
-    // to run at 1080p, tools/state_check.py --audited 6 --fusion 2, while the product instantiations are bit-exact
-    // over the same frames: the same class of fault the audited instantiation showed earlier this round after a
-    // change of a load's type.  Not instantiated; the library launches one frame at a time while an audit is on.)
-    static_assert(NF == 1 || !AUDIT, "the traffic audit counts single-frame launches");
+    // The audited two-frame instantiation exists for BGR only.  (While hipcc wrote the mode exchanges as moves through a
+    // temporary it updated the model wrongly and differently from run to run at 1080p -- tools/state_check.py --audited 6
+    // --fusion 2: 44 k pixels with a different mode count after three audited launches, the product instantiations
+    // bit-exact over the same frames; the class of fault this instantiation showed earlier in the round after a change of
+    // a load's type.  With the exchanges as v_swap_b32 -- BGR, swap_up -- it is bit-exact at 1080p, 4K, on three
+    // streams and on dense models, test_long_run_model_parity_with_audited_steps.  GREY keeps compiler-written
+    // exchanges: its audits count one-frame launches, the library does not pair GREY frames while an audit is on.)
+    static_assert(NF == 1 || !AUDIT || CH == 3, "the audited two-frame instantiation exists for BGR only");
 
     Audit<AUDIT> au;
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
@@ -665,8 +670,10 @@ static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, i
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
-    if (a.frames2) {                     // two frames a launch (never fresh, never audited: the caller's business)
-        if (a.nt_loads) {
+    if (a.frames2) {                     // two frames a launch (never fresh; audited for BGR only: the caller's business)
+        if (a.audit) {
+            launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st);
+        } else if (a.nt_loads) {
             if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st);
             else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st);
         } else {

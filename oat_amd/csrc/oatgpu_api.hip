@@ -1086,7 +1086,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     while (s0 < n) {
         int s1 = s0 + 1;
         while (s1 < n && same(s1, s0)) ++s1;
-        const bool pair = nj == 2 && !rates[s0].fresh && !rates[(size_t)n + s0].fresh && !c->audit_on;
+        const bool pair = nj == 2 && !rates[s0].fresh && !rates[(size_t)n + s0].fresh && !(c->audit_on && c->cfg.channels != 3);
         for (int i = 0; i < (pair ? 1 : nj); ++i) {
             MogLaunch a = mog_launch_base(c, (const uint8_t *)j[i].frames, rates[(size_t)i * n + s0]);
             a.thr_bits = thr_buf(c, j[i].slot);
@@ -1200,7 +1200,7 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     cur.frames = frames_dev; cur.lr = lr; cur.ready = frames_ready;
     cur.slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
     // two frames a launch: only where a second frame can be outstanding, and not under the measurement switches
-    const bool may_fuse = c->fuse == 2 && c->cfg.ring_depth >= 2 && !c->use_graph && !c->serial && !c->expt && !c->audit_on;
+    const bool may_fuse = c->fuse == 2 && c->cfg.ring_depth >= 2 && !c->use_graph && !c->serial && !c->expt && !(c->audit_on && c->cfg.channels != 3);
     int rc = OATGPU_OK;
     if (c->pend_valid) {
         const oatgpu_ctx::FrameJob two[2] = {c->pend, cur};

@@ -90,7 +90,8 @@ struct MogLaunch {
     int fresh;               // 1: model is (re)initialised this frame -> no modes
     // Temporal fusion (kernels_mog.hip "Two frames a launch"): frames2 != nullptr -> the launch advances every
     // stream by TWO frames -- `frames` then `frames2` -- on ONE pass over the model; thr_bits2 takes the second
-    // frame's threshold words, the *2 rates are the second frame's.  Never with fresh, out_bgr / out_mask or audit.
+    // frame's threshold words, the *2 rates are the second frame's.  Never with fresh or out_bgr / out_mask; with audit
+    // for BGR only.
     const uint8_t *frames2;
     u64 *thr_bits2;
     float alphaT2, alpha12, prune2;

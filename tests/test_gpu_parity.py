@@ -1063,13 +1063,13 @@ def test_traffic_audit_counts_what_the_kernel_moves(A):
     u = st.traffic_read()
     # + the threshold mask: one 8-byte word per 64 pixels
     assert u["lane_bytes_read"] == 24 * rows * cols and u["lane_bytes_written"] == 20 * rows * cols + rows * cols // 8
-    # an audit counts one-frame launches: the pipelined path does not pair frames while it is on
+    # two frames a launch (the pipelined path): the second frame adds its 3 B/px and its threshold words, nothing else
     st.traffic_audit(True)
     st.enqueue([still]); st.enqueue([still])
     st.collect(); st.collect()
     u = st.traffic_read()
-    assert u["launches"] == 2 and u["pixels"] == 2 * rows * cols
-    assert u["lane_bytes_read"] == 2 * 24 * rows * cols
+    assert u["launches"] == 1 and u["pixels"] == rows * cols
+    assert u["lane_bytes_read"] == 27 * rows * cols and u["lane_bytes_written"] == 20 * rows * cols + 2 * (rows * cols // 8)
 
 
 def test_mask_filter_and_bsub_background_entry_points(A):
