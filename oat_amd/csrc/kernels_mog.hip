@@ -48,23 +48,23 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // e
     // v_swap_b32 exchanges two VGPRs in one instruction (hipcc writes three moves for a swap through a temporary:
     // 15 instead of 5 vector instructions per exchanged mode -- the kernel is VALU-bound with two frames a launch,
     // and on a dense model every bubbling loop runs in every wave)
-    // Measured (gpurun_out/ab_swap.txt, ab_nt.txt): everyday 4K model 130.9 -> 127.0 us per two-frame launch, 16 x 1080p
-    // 523 -> 507 us; dense model unchanged once its instantiation is out of scratch.  BGR only: the GREY two-frame
-    // instantiation went INTO scratch with it (the asm operands pin registers).
+    // Measured (profiles/r02g_two_frames_ab.txt): everyday 4K model 130.9 -> 127.0 us per two-frame launch, 16 x 1080p
+    // 523 -> 507 us; dense model unchanged once its instantiation is out of scratch.  It is also the form the audited
+    // two-frame instantiation needs to be right (k_mog_fused), so no instantiation relies on compiler-written exchanges
+    // in exec-masked regions any more; the asm operands pin registers, which is why the GREY two-frame instantiations
+    // are compiled for 7 waves/SIMD (at 8 they went into scratch).
 #ifndef OATGPU_NO_VSWAP          // (make variant NAME=noswap DEFS=-DOATGPU_NO_VSWAP: the A/B build)
-    if (CH == 3) {
-        asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
-        asm volatile("v_swap_b32 %0, %1" : "+v"(s.v[i]), "+v"(s.v[i - 1]));
+    asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
+    asm volatile("v_swap_b32 %0, %1" : "+v"(s.v[i]), "+v"(s.v[i - 1]));
 #pragma unroll
-        for (int c = 0; c < CH; ++c) asm volatile("v_swap_b32 %0, %1" : "+v"(s.m[i][c]), "+v"(s.m[i - 1][c]));
-        return;
-    }
-#endif
+    for (int c = 0; c < CH; ++c) asm volatile("v_swap_b32 %0, %1" : "+v"(s.m[i][c]), "+v"(s.m[i - 1][c]));
+#else
     float t;
     t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
     t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
 #pragma unroll
     for (int c = 0; c < CH; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
+#endif
 }
 
 // Iteration MODE of the mode loop on a register resident mixture.
@@ -345,15 +345,15 @@ struct Audit {
 #define OATGPU_F2_WAVES 8
 #endif
 template <int CH, bool AUDIT, bool NTLD, int NF>
-__global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && NTLD) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     // The audited two-frame instantiation exists for BGR only.  (While hipcc wrote the mode exchanges as moves through a
     // temporary it updated the model wrongly and differently from run to run at 1080p -- tools/state_check.py --audited 6
     // --fusion 2: 44 k pixels with a different mode count after three audited launches, the product instantiations
     // bit-exact over the same frames; the class of fault this instantiation showed earlier in the round after a change of
     // a load's type.  With the exchanges as v_swap_b32 -- BGR, swap_up -- it is bit-exact at 1080p, 4K, on three
-    // streams and on dense models, test_long_run_model_parity_with_audited_steps.  GREY keeps compiler-written
-    // exchanges: its audits count one-frame launches, the library does not pair GREY frames while an audit is on.)
+    // streams and on dense models, test_long_run_model_parity_with_audited_steps.  GREY audits count one-frame launches:
+    // the library does not pair GREY frames while an audit is on.)
     static_assert(NF == 1 || !AUDIT || CH == 3, "the audited two-frame instantiation exists for BGR only");
 
     Audit<AUDIT> au;
