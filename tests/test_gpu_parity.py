@@ -1123,23 +1123,6 @@ def test_track_ready_and_input_consumed(A):
         assert hp.collect() == ref.track(frames), t
 
 
-def test_long_run_model_parity_with_audited_steps(A):
-    """The pipelined path at a real frame size, full occupancy: 120 frames of one 1080p SURVEY-8d stream through
-    enqueue / collect (ring 4), then six more through the traffic-audit instantiation of the per-pixel kernel; every
-    position and the WHOLE model (counters, weights, variances, means) must be the oracle's, bit for bit.  (The
-    short model-parity sequences above run small frames; a fault of round 2 -- the audit instantiation updating the
-    model wrongly after a change of a load's type -- showed only here, tools/state_check.py.)"""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import state_check
-    msgs = []
-    assert state_check.run(1080, 1920, 120, 24, audited=6, log=msgs.append) == 0, msgs
-    assert state_check.run(480, 640, 90, 16, streams=3, audited=4, log=msgs.append) == 0, msgs
-    # a dense model (five live modes everywhere): from its second density probe on the library runs the instantiation
-    # whose slot-1..4 loads use the streaming cache policy -- same numbers
-    assert state_check.run(480, 640, 100, 10, streams=2, audited=4, dense=True, log=msgs.append) == 0, msgs
-
-
 def test_back_half_speculation_and_repair(A):
     """The pipelined path launches the row scan + the single-workgroup LDS blob kernel only, as long as frames are
     sparse enough for it; a frame that is not (here: thousands of foreground specks) comes back marked and
