@@ -1319,3 +1319,32 @@ def test_homography_behind_detector_and_kalman(A):
         assert hits >= 40
         hp.set_homography(None)
         hp.close()
+
+
+def test_set_fusion_arguments_and_switching_with_a_frame_registered(A):
+    """oatgpu_set_fusion takes 1 or 2; switching while a frame is only registered sends that frame off first, and the
+    results stay those of one launch a frame."""
+    from oat_amd import ffi
+    rows, cols = 40, 96
+    rng = np.random.default_rng(3)
+    frames = _noisy_sequence(rng, 1, rows, cols, 3, 12, noise=6)
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.05, erode=0, dilate=3, area=(5.0, 1e6), **win)
+    ref = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.05, erode=0, dilate=3, area=(5.0, 1e6), **win)
+    ref.set_fusion(1)
+    for bad in (0, 3, -1):
+        with pytest.raises(ffi.OatGpuError, match="frames_per_launch must be 1 or 2"):
+            hp.set_fusion(bad)
+    got = []
+    for t, f in enumerate(frames):
+        hp.enqueue(list(f))
+        if t in (2, 7):
+            hp.set_fusion(1 if t == 2 else 2)          # frame t is registered, not launched, at this point
+        if hp.outstanding() >= 3:
+            got.append(hp.collect())
+    while hp.outstanding():
+        got.append(hp.collect())
+    want = [ref.track(list(f)) for f in frames]
+    assert got == want
+    for a, b in zip(hp.mog_state()[:4], ref.mog_state()[:4]):
+        assert _eq(np.asarray(a), np.asarray(b))
