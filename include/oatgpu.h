@@ -272,7 +272,10 @@ int oatgpu_track_batch_dev(oatgpu_ctx *ctx, const void *frames_dev, double learn
 
 /* Pipelined form: enqueue returns at once; collect returns results in enqueue
  * order (exactly one result set per enqueued frame set, SURVEY.md 8b token
- * discipline).  Up to ring_depth enqueues may be outstanding. */
+ * discipline).  Up to ring_depth enqueues may be outstanding.  frames_dev must stay
+ * valid and untouched until the frame's result was collected: with oatgpu_set_fusion(2),
+ * the default, its kernels are launched together with the NEXT frame's (or when the
+ * result is asked for), not inside this call. */
 int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate);
 /* Pipelined form for frames in HOST memory (what a camera or a shared-memory SOURCE hands over):
  * the frames are copied to a per-slot device buffer on a copy stream of their own, so the copy of
@@ -288,7 +291,8 @@ int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
  * them, i.e. post() the shared-memory SOURCEs while the device is still computing (the reference releases
  * its source right after its memcpy, FrameFilter.cpp:73-80 / PositionDetector.cpp:78-86).
  * oatgpu_track_ready: 1 if oatgpu_track_collect would return without blocking, 0 if the oldest outstanding
- * result is still being computed (or nothing is outstanding), < 0 on error. */
+ * result is still being computed (or nothing is outstanding), < 0 on error.  (If that oldest frame is still only
+ * registered -- oatgpu_set_fusion -- the call launches it.) */
 int oatgpu_track_input_consumed(oatgpu_ctx *ctx);
 int oatgpu_track_ready(oatgpu_ctx *ctx);
 
