@@ -18,6 +18,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/oatgpu_internal.h include/oatgpu.h
 $(LIB): $(OBJS)
 	@mkdir -p oat_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	python3 tools/isa_hazard_check.py $@      # the gfx950 wide-store data hazard: the binary is checked, DESIGN.md 3b
 
 oracle:
 	$(MAKE) -C oracle

@@ -49,10 +49,10 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // e
     // 15 instead of 5 vector instructions per exchanged mode -- the kernel is VALU-bound with two frames a launch,
     // and on a dense model every bubbling loop runs in every wave)
     // Measured (profiles/r02g_two_frames_ab.txt): everyday 4K model 130.9 -> 127.0 us per two-frame launch, 16 x 1080p
-    // 523 -> 507 us; dense model unchanged once its instantiation is out of scratch.  It is also the form the audited
-    // two-frame instantiation needs to be right (k_mog_fused), so no instantiation relies on compiler-written exchanges
-    // in exec-masked regions any more; the asm operands pin registers, which is why the GREY two-frame instantiations
-    // are compiled for 7 waves/SIMD (at 8 they went into scratch).
+    // 523 -> 507 us; dense model unchanged once its instantiation is out of scratch.  (Round 2 believed the audited
+    // two-frame instantiation NEEDED this form to be right; it only moved the register allocation away from st_rec's
+    // wide-store hazard -- DESIGN.md 3b.  The asm operands pin registers, which is why the GREY two-frame
+    // instantiations are compiled for 7 waves/SIMD: at 8 they went into scratch.)
 #ifndef OATGPU_NO_VSWAP          // (make variant NAME=noswap DEFS=-DOATGPU_NO_VSWAP: the A/B build)
     asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
     asm volatile("v_swap_b32 %0, %1" : "+v"(s.v[i]), "+v"(s.v[i - 1]));
@@ -347,13 +347,9 @@ struct Audit {
 template <int CH, bool AUDIT, bool NTLD, int NF>
 __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
-    // The audited two-frame instantiation exists for BGR only.  (While hipcc wrote the mode exchanges as moves through a
-    // temporary it updated the model wrongly and differently from run to run at 1080p -- tools/state_check.py --audited 6
-    // --fusion 2: 44 k pixels with a different mode count after three audited launches, the product instantiations
-    // bit-exact over the same frames; the class of fault this instantiation showed earlier in the round after a change of
-    // a load's type.  With the exchanges as v_swap_b32 -- BGR, swap_up -- it is bit-exact at 1080p, 4K, on three
-    // streams and on dense models, test_long_run_model_parity_with_audited_steps.  GREY audits count one-frame launches:
-    // the library does not pair GREY frames while an audit is on.)
+    // The audited two-frame instantiation exists for BGR only (GREY audits count one-frame launches: the library does
+    // not pair GREY frames while an audit is on).  Round 2's "instantiation the compiler is touchy about" was the
+    // wide-store data hazard of st_rec below, root-caused in round 3.
     static_assert(NF == 1 || !AUDIT || CH == 3, "the audited two-frame instantiation exists for BGR only");
 
     Audit<AUDIT> au;
@@ -406,10 +402,8 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     auto ld_rec = [&](int k, float &v, float *m) {                  // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
         if (CH == 3) {
-            // (the default-policy load stays a HIP float4 load: as `*(const f32x4 *)rp` -- the ext-vector type the
-            // nontemporal builtin needs -- the traffic-audit instantiation of this kernel, and only it, updated
-            // the model wrongly and differently from run to run on ROCm 7.2; tools/state_check.py and
-            // test_long_run_model_parity_with_audited_steps catch that class of fault)
+            // (round 2 kept this a HIP float4 load because the ext-vector form "broke" the audit instantiation: that was
+            // the register allocation moving and st_rec's wide-store hazard striking, DESIGN.md 3b -- not the load)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             if (NTLD && k >= 1) {
                 const f32x4 q = __builtin_nontemporal_load((const f32x4 *)rp);
@@ -430,6 +424,13 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             q.z = __builtin_bit_cast(unsigned, m[1]); q.w = __builtin_bit_cast(unsigned, m[2]);
             if (k >= 1) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
             else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
+            // gfx950 wide-store data hazard (tools/store_hazard_repro.hip): a store of more than 64
+            // bits reads its data VGPRs for a few cycles after issue, and hipcc (ROCm 7.2) -- which takes a buffer
+            // store with an SGPR soffset to be exempt -- may overwrite one of them in the very next instruction.
+            // That is what made the audited two-frame instantiation store `16` (its byte counter's increment) as the
+            // mean / variance of lanes 12..15 of every 16 in round 2.  Two wait states with the data registers still
+            // live behind every record store; tools/isa_hazard_check.py verifies the shipped binary.
+            asm volatile("s_nop 1" :: "v"(q));
         } else {
             u32x2 q;
             q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
