@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 4     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames */
+#define OATGPU_ABI_VERSION 5     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2) */
 
 enum {
     OATGPU_OK = 0,
@@ -69,7 +69,8 @@ typedef struct oatgpu_config {
     float var_init;            /* 15      */
     float var_min;             /* 4       */
     float var_max;             /* 75      */
-    float ct;                  /* 0.05    */
+    float ct;                  /* 0.05; must lie in [0, 0.5): OpenCV accepts any value, the kernel relies on a matched
+                                  mode (weight >= alpha (1 - ct)) never being prunable (weight < alpha ct) */
     float tau;                 /* 0.5     */
     int32_t detect_shadows;    /* 1       */
     int32_t shadow_value;      /* 127     */
@@ -152,16 +153,21 @@ int oatgpu_set_stream(oatgpu_ctx *ctx, void *hip_stream);
 void *oatgpu_get_stream(oatgpu_ctx *ctx);
 int oatgpu_synchronize(oatgpu_ctx *ctx);
 
-/* Frames per launch of the fused per-pixel kernel on the pipelined path (oatgpu_track_enqueue[_dev],
- * oatgpu_track_sequence_dev), 1 or 2; default 2.  The MOG2 update is a recurrence per pixel, so two
- * consecutive frames of a stream can be taken on ONE pass over its model (kept in registers between them):
- * with 2, an enqueue only registers its frame and the kernels are launched when the next frame is enqueued --
- * or as soon as the frame's result is asked for (oatgpu_track_collect / oatgpu_track_ready reaching that
- * frame) or any synchronous entry point runs, then for the one frame alone; a caller that collects every
- * frame before it enqueues the next (oatgpu_track_batch*, a camera-bound component loop) never waits for a
- * second frame.  Results, their order, the threshold images and the model are bit-identical either way
- * (FrameFilter.cpp:59-98 / PositionDetector.cpp:58-99: one token out per token in, in order).
- * The caller's frame of oatgpu_track_enqueue_dev must stay valid until its result was collected (as before).
+/* Frames per launch of the fused per-pixel kernel on the pipelined path, 1 or 2.  The MOG2 update is a recurrence
+ * per pixel, so two consecutive frames of a stream can be taken on ONE pass over its model (kept in registers
+ * between them).  With 2, an enqueue only REGISTERS its frame; the kernels are launched when the next frame is
+ * enqueued -- or as soon as the frame's result is asked for (oatgpu_track_collect / oatgpu_track_ready reaching
+ * that frame, oatgpu_track_input_consumed) or any synchronous entry point runs, then for the one frame alone; a
+ * caller that collects every frame before it enqueues the next (oatgpu_track_batch*, a camera-bound component
+ * loop) never waits for a second frame.  Results, their order, the threshold images and the model are
+ * bit-identical either way (FrameFilter.cpp:59-98 / PositionDetector.cpp:58-99: one token out per token in, in
+ * order).
+ * DEFAULT (no call): two frames a launch wherever the LIBRARY owns the frame's lifetime -- oatgpu_track_enqueue
+ * (host frames: copied to a staging slot inside the call) and oatgpu_track_sequence_dev (all frames handed over at
+ * once) -- and ONE frame a launch for oatgpu_track_enqueue_dev, whose kernel is then queued inside the call as it
+ * always was, so a caller that reuses its device buffer in stream order stays correct.  oatgpu_set_fusion(2) opts
+ * oatgpu_track_enqueue_dev in: from then on a frame handed to it must stay valid and UNTOUCHED until its result
+ * was collected or oatgpu_track_input_consumed returned.  oatgpu_set_fusion(1) switches pairing off everywhere.
  * While a traffic audit is on (oatgpu_traffic_audit) GREY contexts launch one frame at a time. */
 int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
@@ -272,10 +278,11 @@ int oatgpu_track_batch_dev(oatgpu_ctx *ctx, const void *frames_dev, double learn
 
 /* Pipelined form: enqueue returns at once; collect returns results in enqueue
  * order (exactly one result set per enqueued frame set, SURVEY.md 8b token
- * discipline).  Up to ring_depth enqueues may be outstanding.  frames_dev must stay
- * valid and untouched until the frame's result was collected: with oatgpu_set_fusion(2),
- * the default, its kernels are launched together with the NEXT frame's (or when the
- * result is asked for), not inside this call. */
+ * discipline).  Up to ring_depth enqueues may be outstanding.  By default the per-pixel
+ * kernel that reads frames_dev is queued on the context's stream inside this call; after
+ * oatgpu_set_fusion(2) it may go out with the NEXT frame's instead, and frames_dev must stay
+ * valid and untouched until the frame's result was collected or oatgpu_track_input_consumed
+ * returned (see oatgpu_set_fusion). */
 int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double learning_rate);
 /* Pipelined form for frames in HOST memory (what a camera or a shared-memory SOURCE hands over):
  * the frames are copied to a per-slot device buffer on a copy stream of their own, so the copy of
@@ -285,14 +292,16 @@ int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double lea
 int oatgpu_track_enqueue(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n, double learning_rate);
 int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
 
-/* Pipelined callers that hand over HOST frames (the batched drop-in component, host/oat_track_hip.cpp):
- * oatgpu_track_input_consumed blocks until the frames of the most recent oatgpu_track_enqueue have been
- * read out of the caller's buffers (H2D copies done) -- from then on the caller may release or overwrite
+/* oatgpu_track_input_consumed blocks until every frame handed over so far has been read out of the caller's
+ * buffers -- host frames (oatgpu_track_enqueue): their H2D copies are done; device frames
+ * (oatgpu_track_enqueue_dev): the per-pixel kernel that reads them has finished (a frame that was only
+ * registered, oatgpu_set_fusion(2), is launched first).  From then on the caller may release or overwrite
  * them, i.e. post() the shared-memory SOURCEs while the device is still computing (the reference releases
  * its source right after its memcpy, FrameFilter.cpp:73-80 / PositionDetector.cpp:78-86).
  * oatgpu_track_ready: 1 if oatgpu_track_collect would return without blocking, 0 if the oldest outstanding
  * result is still being computed (or nothing is outstanding), < 0 on error.  (If that oldest frame is still only
- * registered -- oatgpu_set_fusion -- the call launches it.) */
+ * registered -- oatgpu_set_fusion -- the call launches it; if its speculative back half declined the frame, the
+ * call launches the global kernels on it and reports 0 until they are done.) */
 int oatgpu_track_input_consumed(oatgpu_ctx *ctx);
 int oatgpu_track_ready(oatgpu_ctx *ctx);
 
@@ -303,6 +312,12 @@ int oatgpu_track_ready(oatgpu_ctx *ctx);
  * nothing may be outstanding when it is called. */
 int oatgpu_track_sequence_dev(oatgpu_ctx *ctx, const void *const *frames_dev, int32_t n_frames,
                               double learning_rate, oatgpu_position *out);
+/* The same, also reporting WHEN each frame's result was collected: done_s[t] = seconds since the call was
+ * entered (steady clock) at which frame t's result set had been handed out.  With the ring kept full the
+ * difference done_s[t+K] - done_s[t] is the steady-state time of K steps, free of the pipeline's fill and drain
+ * (bench.py's block timing).  done_s may be NULL. */
+int oatgpu_track_sequence_dev_timed(oatgpu_ctx *ctx, const void *const *frames_dev, int32_t n_frames,
+                                    double learning_rate, oatgpu_position *out, double *done_s);
 int oatgpu_track_outstanding(const oatgpu_ctx *ctx);
 
 /* ---- parity taps / model checkpoint (not in the reference; for tests and resume) ---- */

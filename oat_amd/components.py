@@ -329,14 +329,33 @@ class HotPath(_Context):
         self._held = getattr(self, "_held", [])
         self._held.append(fs)
 
-    def enqueue_dev(self, dev_ptr):
+    def enqueue_dev(self, dev_ptr, keepalive=None):
+        """Pipelined device-frame form (oatgpu_track_enqueue_dev): dev_ptr -> n_streams*rows*cols*channels bytes.
+        By default the per-pixel kernel that reads the frame is queued on the context's stream inside the call.
+        After set_fusion(2) it may go out with the NEXT frame's (two frames a launch): the buffer must then stay
+        valid and untouched until the frame's result was collected or input_consumed() returned -- pass the owning
+        object (a torch tensor) as `keepalive` and it is held here until the matching collect()."""
         self._chk(self.lib.oatgpu_track_enqueue_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_))
+        self._held = getattr(self, "_held", [])
+        self._held.append(keepalive)
+
+    def input_consumed(self):
+        """Block until every frame handed over so far has been read out of the caller's buffers
+        (oatgpu_track_input_consumed): host frames copied, device frames read by their per-pixel kernel."""
+        self._chk(self.lib.oatgpu_track_input_consumed(self.ctx))
 
     def collect(self):
         self._chk(self.lib.oatgpu_track_collect(self.ctx, self._pos))
         if getattr(self, "_held", None):
             self._held.pop(0)
         return self._out()
+
+    def ready(self):
+        """True if collect() would return without blocking (oatgpu_track_ready)."""
+        rc = self.lib.oatgpu_track_ready(self.ctx)
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
 
     def outstanding(self):
         return self.lib.oatgpu_track_outstanding(self.ctx)
@@ -357,6 +376,10 @@ class HotPath(_Context):
 
     def set_stream(self, hip_stream):
         self._chk(self.lib.oatgpu_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def get_stream(self):
+        """hipStream_t (as an integer) the per-pixel kernel is launched on (oatgpu_get_stream)."""
+        return int(self.lib.oatgpu_get_stream(self.ctx) or 0)
 
     def synchronize(self):
         self._chk(self.lib.oatgpu_synchronize(self.ctx))

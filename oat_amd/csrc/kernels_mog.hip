@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         if (svm) st_rec(k, pm.v[k], pm.m[k]);
         AU_DW(sw, true);
         AU_REC(svm, true);
-        if (k >= 1 && k < nnew && pm.w[k] != 0.f) newcnt |= 1 << (kLiveShift + k);
+        if (k >= 1 && k < nnew && __float_as_uint(pm.w[k]) != 0u) newcnt |= 1 << (kLiveShift + k);   // (bits: an imported -0.f is live)
     }
     const bool sc = work && (newcnt != cnt || a.fresh);
     if (sc) nmbase[coff] = (uint8_t)newcnt;
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_state_import(Geom g, float *state, uint
         const int p = y * g.Wp + x;
         int cnt = modes_used[i];
         for (int k = 1; k < nmix && k < (int)modes_used[i]; ++k)            // live hints of slots 1..n-1
-            if (weight[i * nmix + k] != 0.f) cnt |= 1 << (kLiveShift + k);
+            if (__float_as_uint(weight[i * nmix + k]) != 0u) cnt |= 1 << (kLiveShift + k);     // bits, not value: -0.f must be stored back as it came
         *count_elem(g, state, nmodes, p) = (uint8_t)cnt;
         for (int k = 0; k < nmix; ++k) {
             *w_elem(g, state, ch, k, p) = weight[i * nmix + k];

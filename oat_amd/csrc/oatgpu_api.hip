@@ -9,6 +9,7 @@
 #include "oatgpu_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -92,7 +93,12 @@ struct oatgpu_ctx {
     // centroid is finished, on the host, in the reference's double arithmetic
     bool homo_on = false;
     double homo[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    int fuse = 2;
+    int fuse = 0;                                     // 0: default -- pair where the library owns the frame's lifetime
+                                                      // (host frames, track_sequence_dev), not for oatgpu_track_enqueue_dev
+    bool in_sequence = false;                         // inside oatgpu_track_sequence_dev: its frames are all in hand
+    hipEvent_t ev_in = nullptr;                       // stream A has read every frame handed over so far (input_consumed)
+    bool dev_unconsumed = false;                      // device frames were enqueued since the last input_consumed
+    std::vector<char> slot_repair;                    // per ring slot: the global kernels are redoing this frame (ready/quiesce)
     bool pend_valid = false;
     FrameJob pend;
     unsigned long long launched_total = 0;            // frames whose kernels are out (<= enq_total)
@@ -310,6 +316,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->kal.state);
     hipFree(c->audit_dev);
     hipFree(c->frames_ring);
+    if (c->ev_in) hipEventDestroy(c->ev_in);
     for (auto e : c->copy_ev) hipEventDestroy(e);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
@@ -450,6 +457,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         c->slot_filtered.assign(c->ring_slots, 0);
         c->slot_spec.assign(c->ring_slots + 1, 0);
         c->slot_q.assign(c->ring_slots + 1, 0);
+        c->slot_repair.assign(c->ring_slots + 1, 0);
         c->slot_ev.resize(c->ring_slots);
         for (int i = 0; i < c->ring_slots; ++i) c->slot_ev[i] = i;
         for (auto &e : c->ring_ev)
@@ -586,13 +594,17 @@ static u64 *thr_buf(oatgpu_ctx *c, int parity)
 // wait until both HIP streams have drained.
 static int flush_pending(oatgpu_ctx *c);
 
+static int repair_outstanding(oatgpu_ctx *c);
+
 static int quiesce(oatgpu_ctx *c)
 {
     const int frc = flush_pending(c);
     if (frc) return frc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
-    return OATGPU_OK;
+    // Outstanding frames whose speculative back half declined them are redone NOW, while their threshold bits are still
+    // in their ring slots: the single-stage calls that follow a quiesce() write theirs into slot 0's buffer.
+    return repair_outstanding(c);
 }
 
 static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rate &r)
@@ -1014,7 +1026,9 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
 
 extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, double lr)
 {
-    return enqueue_frames(c, frames_dev, lr, nullptr);
+    const int rc = enqueue_frames(c, frames_dev, lr, nullptr);
+    if (!rc) c->dev_unconsumed = true;
+    return rc;
 }
 
 extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_host, int32_t n, double lr)
@@ -1200,12 +1214,19 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     cur.frames = frames_dev; cur.lr = lr; cur.ready = frames_ready;
     cur.slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
     // two frames a launch: only where a second frame can be outstanding, and not under the measurement switches
-    const bool may_fuse = c->fuse == 2 && c->cfg.ring_depth >= 2 && !c->use_graph && !c->serial && !c->expt && !(c->audit_on && c->cfg.channels != 3);
+    const bool want_pair = c->fuse == 2 || (c->fuse == 0 && (frames_ready != nullptr || c->in_sequence));
+    const bool may_fuse = want_pair && c->cfg.ring_depth >= 2 && !c->use_graph && !c->serial && !c->expt && !(c->audit_on && c->cfg.channels != 3);
     int rc = OATGPU_OK;
     if (c->pend_valid) {
         const oatgpu_ctx::FrameJob two[2] = {c->pend, cur};
         c->pend_valid = false;
         rc = launch_jobs(c, two, 2);
+        if (rc) {                         // the registered frame went down with this one: it is no longer outstanding
+            c->enq_total--;
+            c->ring_count--;
+            c->err += " (the frame registered by the previous enqueue was dropped with this one)";
+            return rc;
+        }
     } else if (may_fuse) {
         c->pend = cur;
         c->pend_valid = true;
@@ -1215,6 +1236,50 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     if (rc) return rc;
     c->enq_total++;
     c->ring_count++;
+    return OATGPU_OK;
+}
+
+// Speculation and repair (see lds_spec).  A frame the single-workgroup LDS kernel declined comes back marked; the global
+// kernels then redo it from its threshold bits, which stay in its ring slot until its result was collected.
+static bool slot_needs_global(const oatgpu_ctx *c, int slot)
+{
+    if (!c->slot_spec[slot]) return false;
+    const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
+    for (int s = 0; s < c->cfg.n_streams; ++s) if (r[s].valid == kNeedsGlobal) return true;
+    return false;
+}
+
+// ... on the frame's scratch set's stream, behind whatever later frame that is busy with; the slot's ring event is
+// recorded again behind them.  Not waited for here.
+static int launch_repair(oatgpu_ctx *c, int slot)
+{
+    const int q = c->slot_q[slot];
+    hipStream_t B = c->serial ? c->stream : c->stream_b[q];
+    const int rc = back_half(c, c->bb[q], thr_buf(c, slot), 0, c->cfg.n_streams, slot, B, nullptr, -1, -1, kBlobGlobal);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));
+    c->slot_ev[slot] = slot;
+    c->slot_repair[slot] = 1;
+    c->slot_spec[slot] = 0;
+    c->lds_spec = false;
+    c->lds_streak = 0;
+    return OATGPU_OK;
+}
+
+// quiesce(): every outstanding frame is done; redo the declined ones and wait for them
+static int repair_outstanding(oatgpu_ctx *c)
+{
+    bool any = false;
+    for (unsigned long long t = c->col_total; t < c->col_total + (unsigned long long)c->ring_count; ++t) {
+        const int slot = (int)(t % (unsigned long long)c->ring_slots);
+        if (c->slot_repair[slot] || !slot_needs_global(c, slot)) continue;
+        const int rc = launch_repair(c, slot);
+        if (rc) return rc;
+        any = true;
+    }
+    if (any)
+        for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
+    if (any && c->serial) HIPCHK(c, hipStreamSynchronize(c->stream));
     return OATGPU_OK;
 }
 
@@ -1229,24 +1294,18 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
     }
     HIPCHK(c, hipEventSynchronize(c->ring_ev[c->slot_ev[slot]]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
-    {   // speculation bookkeeping (see lds_spec)
+    if (!c->slot_repair[slot] && slot_needs_global(c, slot)) {
+        const int rc = launch_repair(c, slot);
+        if (rc) return rc;
+    }
+    if (c->slot_repair[slot]) {                            // (launched here, by oatgpu_track_ready or by a quiesce())
+        HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+        c->slot_repair[slot] = 0;
+    } else {
         constexpr int kSpecAfter = 16;
-        bool all_lds = true, repair = false;
-        for (int s = 0; s < c->cfg.n_streams; ++s) {
-            if (r[s].valid == kNeedsGlobal) repair = true;
-            if (r[s].path != 1) all_lds = false;
-        }
-        if (repair) {
-            // the frame's threshold bits are still in its ring slot (a slot is reused only after this collect);
-            // its scratch set's stream runs the global kernels behind whatever later frame it is busy with
-            const int q = c->slot_q[slot];
-            hipStream_t B = c->serial ? c->stream : c->stream_b[q];
-            const int rc = back_half(c, c->bb[q], thr_buf(c, slot), 0, c->cfg.n_streams, slot, B, nullptr, -1, -1, kBlobGlobal);
-            if (rc) return rc;
-            HIPCHK(c, hipStreamSynchronize(B));
-            c->lds_spec = false;
-            c->lds_streak = 0;
-        } else if (all_lds) {
+        bool all_lds = true;
+        for (int s = 0; s < c->cfg.n_streams; ++s) if (r[s].path != 1) all_lds = false;
+        if (all_lds) {
             if (++c->lds_streak >= kSpecAfter) c->lds_spec = true;
         } else {
             c->lds_streak = 0;
@@ -1266,6 +1325,15 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
 extern "C" int oatgpu_track_input_consumed(oatgpu_ctx *c)
 {
     if (!c) return OATGPU_E_INVALID;
+    if (c->dev_unconsumed) {             // device frames: the per-pixel kernels that read them must have finished
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        const int frc = flush_pending(c);
+        if (frc) return frc;
+        if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_in));
+        c->dev_unconsumed = false;
+    }
     if (c->last_copy_slot < 0) return OATGPU_OK;
     HIPCHK(c, hipEventSynchronize(c->copy_ev[c->last_copy_slot]));
     return OATGPU_OK;
@@ -1280,32 +1348,45 @@ extern "C" int oatgpu_track_ready(oatgpu_ctx *c)
         const int frc = flush_pending(c);
         if (frc) return frc;
     }
-    const hipError_t e = hipEventQuery(c->ring_ev[c->slot_ev[slot]]);
-    if (e == hipSuccess) return 1;
+    const hipError_t e = hipEventQuery(c->ring_ev[c->slot_repair[slot] ? slot : c->slot_ev[slot]]);
     if (e == hipErrorNotReady) return 0;
-    return fail(c, OATGPU_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+    if (!c->slot_repair[slot] && slot_needs_global(c, slot)) {   // declined by the LDS kernel: collect would block on the
+        const int rc = launch_repair(c, slot);                    // global kernels -- start them, not ready yet
+        return rc ? rc : 0;
+    }
+    return 1;
+}
+
+extern "C" int oatgpu_track_sequence_dev_timed(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
+                                               oatgpu_position *out, double *done_s)
+{
+    if (!c || !frames_dev || !out || n_frames < 0) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "track_sequence while enqueued results are outstanding");
+    const int n = c->cfg.n_streams;
+    const auto t0 = std::chrono::steady_clock::now();
+    int got = 0, rc = OATGPU_OK;
+    auto collect_one = [&]() {
+        const int r = oatgpu_track_collect(c, out + (size_t)got * n);
+        if (!r && done_s) done_s[got] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++got;
+        return r;
+    };
+    c->in_sequence = true;               // every frame of the sequence is in hand: pairing is safe (oatgpu_set_fusion)
+    for (int t = 0; t < n_frames && !rc; ++t) {
+        if (c->ring_count == c->cfg.ring_depth) rc = collect_one();
+        if (!rc) rc = oatgpu_track_enqueue_dev(c, frames_dev[t], lr);
+    }
+    c->in_sequence = false;
+    while (!rc && c->ring_count) rc = collect_one();
+    c->dev_unconsumed = false;           // all collected: every frame was read
+    return rc;
 }
 
 extern "C" int oatgpu_track_sequence_dev(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
                                          oatgpu_position *out)
 {
-    if (!c || !frames_dev || !out || n_frames < 0) return fail(c, OATGPU_E_INVALID, "null argument");
-    if (c->ring_count) return fail(c, OATGPU_E_INVALID, "track_sequence while enqueued results are outstanding");
-    const int n = c->cfg.n_streams;
-    int got = 0;
-    for (int t = 0; t < n_frames; ++t) {
-        if (c->ring_count == c->cfg.ring_depth) {
-            const int rc = oatgpu_track_collect(c, out + (size_t)got++ * n);
-            if (rc) return rc;
-        }
-        const int rc = oatgpu_track_enqueue_dev(c, frames_dev[t], lr);
-        if (rc) return rc;
-    }
-    while (c->ring_count) {
-        const int rc = oatgpu_track_collect(c, out + (size_t)got++ * n);
-        if (rc) return rc;
-    }
-    return OATGPU_OK;
+    return oatgpu_track_sequence_dev_timed(c, frames_dev, n_frames, lr, out, nullptr);
 }
 
 extern "C" int oatgpu_track_outstanding(const oatgpu_ctx *c) { return c ? c->ring_count : 0; }

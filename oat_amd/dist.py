@@ -86,19 +86,22 @@ class FrameScatterPipe:
             local = pipe.take(t)                               # ... step t is taken and computed
             compute(local)
 
-    post(t) uses buffer slot t % depth, so take(t)'s tensor stays valid until post(t + depth).  A frame handed to
-    HotPath.enqueue_dev must stay untouched until its result was collected (the library may launch its kernels only
-    with the NEXT frame: two frames a launch, oatgpu_set_fusion): collect step t before post(t + depth), or make
-    depth the ring depth + 1.  Backend "nccl"
-    (= RCCL) on the GPU box; the tests drive the same code over gloo.  Unmeasured on multi-GPU hardware so far
-    (the builder has one GPU at a time): the driver's SCALE run uses per-rank ingest, not this path."""
+    post(t) uses buffer slot t % depth, so take(t)'s tensor stays valid until post(t + depth) -- and post(t + depth)
+    must not start before the kernel that READS the slot has finished: the receive runs on RCCL's stream, the
+    per-pixel kernel on the hot path's.  Pass the HotPath as `consumer`: post() then calls its input_consumed()
+    (oatgpu_track_input_consumed) before it reuses a slot, and take() orders the consumer's HIP stream behind the
+    transfer with a stream-to-stream wait instead of blocking the host (without a consumer it synchronises the
+    device's current stream, which serialises the overlap the pipe exists for).  Backend "nccl" (= RCCL) on the
+    GPU box; the tests drive the same code over gloo.  Unmeasured on multi-GPU hardware so far (the builder has
+    one GPU at a time): the driver's SCALE run uses per-rank ingest, not this path."""
 
-    def __init__(self, n_streams_total, frame_shape, device, src=0, group=None, depth=2):
+    def __init__(self, n_streams_total, frame_shape, device, src=0, group=None, depth=2, consumer=None):
         self.total, self.shape, self.device, self.src, self.group = n_streams_total, tuple(frame_shape), device, src, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.per = -(-n_streams_total // self.world)
         self.mine = stream_partition(n_streams_total, self.world, self.rank)
         self.depth = depth
+        self.consumer = consumer
         self.buf = [torch.empty((self.per,) + self.shape, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.work = [None] * depth          # outstanding requests of the slot
         self.keep = [None] * depth          # root: the frame tensor being sent out of
@@ -108,6 +111,8 @@ class FrameScatterPipe:
         k = t % self.depth
         if self.work[k] is not None:
             raise RuntimeError(f"slot of step {self.step_of[k]} was never taken")
+        if self.step_of[k] is not None and self.consumer is not None:
+            self.consumer.input_consumed()          # the kernel reading this slot's previous frames has finished
         ops = []
         if self.rank == self.src:
             fr = frames_root if frames_root.device == self.buf[k].device else frames_root.to(self.device, non_blocking=True)
@@ -134,7 +139,12 @@ class FrameScatterPipe:
         for w in self.work[k]:
             w.wait()
         if self.buf[k].is_cuda:
-            torch.cuda.current_stream(self.buf[k].device).synchronize()   # the hot path runs on its own HIP streams
+            cur = torch.cuda.current_stream(self.buf[k].device)
+            if self.consumer is not None and self.consumer.get_stream():
+                # the hot path runs on its own HIP streams: order ITS stream behind the transfer, never the host
+                torch.cuda.ExternalStream(self.consumer.get_stream(), device=self.buf[k].device).wait_stream(cur)
+            else:
+                cur.synchronize()
         self.work[k] = None
         self.keep[k] = None
         return self.buf[k][:len(self.mine)]

@@ -53,7 +53,7 @@ class Traffic(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 4          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 5          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -95,6 +95,8 @@ SIGNATURES = {
     "oatgpu_track_enqueue": (C.c_int, [_ctx, C.POINTER(_u8p), C.c_int32, C.c_double]),
     "oatgpu_track_enqueue_dev": (C.c_int, [_ctx, C.c_void_p, C.c_double]),
     "oatgpu_track_sequence_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position)]),
+    "oatgpu_track_sequence_dev_timed": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position),
+                                                  C.POINTER(C.c_double)]),
     "oatgpu_track_collect": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_track_outstanding": (C.c_int, [_ctx]),
     "oatgpu_track_input_consumed": (C.c_int, [_ctx]),

@@ -855,6 +855,7 @@ def test_kalman_filter_on_the_batch_matches_oracle(A, pipelined):
     hp = A.HotPath(rows, cols, n_streams=n, ring_depth=4, adaptation_coeff=0.0, erode=0, dilate=3,
                    v_thresh=(200, 256), area=(4.0, 1e6))
     hp.set_kalman(True, **kw)
+    hp.set_fusion(2)                 # device frames pair only on request (oatgpu_set_fusion)
     p = O.hsv_params(v_lo=200, v_hi=256, erode=0, dilate=3, min_area=4.0, max_area=1e6)
     orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
     kal = [O.Kalman(**kw) for _ in range(n)]
@@ -1348,3 +1349,147 @@ def test_set_fusion_arguments_and_switching_with_a_frame_registered(A):
     assert got == want
     for a, b in zip(hp.mog_state()[:4], ref.mog_state()[:4]):
         assert _eq(np.asarray(a), np.asarray(b))
+
+
+# ------------------------------------------- round 3: frame lifetime, repairs under single-stage calls --
+
+def _frames_per_launch(hp, run):
+    hp.profile(1)
+    hp.profile_reset()
+    run()
+    p = hp.profile_read()
+    hp.profile(0)
+    return p["mog_frames"] / max(p["steps"], 1)
+
+
+def test_default_fusion_pairs_only_where_the_library_owns_the_frames(A):
+    """oatgpu_set_fusion's default: host frames (copied to a staging slot) and track_sequence_dev (all frames in hand)
+    take two frames a launch; oatgpu_track_enqueue_dev queues its kernel inside the call -- one frame a launch --
+    until oatgpu_set_fusion(2) opts in."""
+    import torch
+    rows, cols = 96, 128
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, (1, rows, cols, 3)).astype(np.uint8) for _ in range(9)]
+    bufs = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+
+    def mk():
+        hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.02, dilate=3)
+        hp.track(list(frames[0]))
+        return hp
+
+    def dev_loop(hp):
+        def run():
+            for b in bufs[1:]:
+                hp.enqueue_dev(b.data_ptr(), keepalive=b)
+                if hp.outstanding() == 4:
+                    hp.collect()
+            while hp.outstanding():
+                hp.collect()
+        return run
+
+    def host_loop(hp):
+        def run():
+            for f in frames[1:]:
+                hp.enqueue(list(f))
+                if hp.outstanding() == 4:
+                    hp.collect()
+            while hp.outstanding():
+                hp.collect()
+        return run
+    hp = mk()
+    assert _frames_per_launch(hp, dev_loop(hp)) == 1.0
+    hp = mk()
+    hp.set_fusion(2)
+    assert _frames_per_launch(hp, dev_loop(hp)) == 2.0
+    hp = mk()
+    assert _frames_per_launch(hp, host_loop(hp)) == 2.0
+    hp = mk()
+    assert _frames_per_launch(hp, lambda: hp.track_sequence_dev([b.data_ptr() for b in bufs[1:]])) == 2.0
+    hp = mk()
+    hp.set_fusion(1)
+    assert _frames_per_launch(hp, host_loop(hp)) == 1.0
+
+
+def test_device_buffer_reused_in_stream_order_and_input_consumed(A):
+    """(1) Default: a caller that refills ONE device buffer on the context's stream between enqueue_dev calls gets
+    the right results (the kernel was queued inside the call).  (2) With oatgpu_set_fusion(2) the buffer may be
+    overwritten once oatgpu_track_input_consumed returned (the registered frame is launched first)."""
+    import torch
+    from oat_amd.synth import disc_hsv_window
+    rows, cols, nfr = 120, 160, 14
+    rng = np.random.default_rng(5)
+    frames = _noisy_sequence(rng, 1, rows, cols, 3, nfr, 8)
+    kw = dict(n_streams=1, ring_depth=4, adaptation_coeff=0.02, erode=0, dilate=3, area=(4.0, 1e9), **disc_hsv_window())
+    ref = A.HotPath(rows, cols, **kw)
+    want = [ref.track(list(f)) for f in frames]
+    pinned = [torch.from_numpy(f).pin_memory() for f in frames]
+    for fusion in (None, 2):
+        hp = A.HotPath(rows, cols, **kw)
+        if fusion:
+            hp.set_fusion(fusion)
+        buf = torch.empty((1, rows, cols, 3), dtype=torch.uint8, device="cuda:0")
+        st = torch.cuda.ExternalStream(hp.get_stream(), device=torch.device("cuda:0"))
+        got = []
+        for t in range(nfr):
+            if fusion:
+                hp.input_consumed()                      # the kernel that read `buf` has finished (launches a registered frame)
+            with torch.cuda.stream(st):
+                buf.copy_(pinned[t], non_blocking=True)  # stream order on the context's own stream
+            hp.enqueue_dev(buf.data_ptr())
+            if hp.outstanding() == 3:
+                got.append(hp.collect())
+        while hp.outstanding():
+            got.append(hp.collect())
+        assert got == want, fusion
+        nm_a, w_a, v_a, m_a, _ = hp.mog_state(0)
+        nm_b, w_b, v_b, m_b, _ = ref.mog_state(0)
+        assert (nm_a == nm_b).all() and (w_a == w_b).all() and (v_a == v_b).all() and (m_a == m_b).all()
+
+
+def test_declined_frame_survives_single_stage_calls_and_ready(A):
+    """A frame the single-workgroup LDS kernel declined is redone by the global kernels from the threshold bits in
+    its ring slot.  A single-stage call made while it is outstanding writes ITS threshold bits into slot 0's buffer:
+    the quiesce() in front of it must have redone the frame by then.  oatgpu_track_ready on such a
+    frame starts the redo and reports 0 until it is done; collect then hands out the oracle's result."""
+    import time
+    rows, cols = 240, 320
+    rng = np.random.default_rng(12)
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=0, dilate=2, min_area=4.0, max_area=1e9)
+    base = rng.integers(90, 140, (rows, cols, 3)).astype(np.int16)
+
+    def frame(t, busy):
+        f = np.clip(base + rng.integers(-5, 6, base.shape), 0, 255).astype(np.uint8)
+        if t > 0:
+            f[60:80, 70 + 3 * t:95 + 3 * t] = (255, 64, 0)
+            if busy:
+                f[rng.random((rows, cols)) < 0.08] = (255, 64, 0)
+        return f
+    hsv_probe = O.bgr2hsv(frame(1, False))
+    for use_ready in (False, True):
+        hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.01, erode=0, dilate=2, area=(4.0, 1e9), **win)
+        orc = O.Mog2(rows, cols, 3)
+        frames = [frame(t, False) for t in range(5)]
+        for f in frames[:4]:
+            got = hp.track([f])[0]
+            _same_detection(got, O.chain_step(orc, f, 0.01, p)[0], "warm")
+        busy = frame(5, True)
+        calm = frame(6, False)
+        # the busy frame lands in ring slot 0 (four synchronous steps went before it: 4 % 4 == 0)
+        hp.enqueue([busy])
+        hp.enqueue([calm])
+        if use_ready:
+            t0 = time.perf_counter()
+            while not hp.ready():
+                assert time.perf_counter() - t0 < 10.0
+                time.sleep(0.0005)
+        else:
+            import ctypes as C
+            from oat_amd import ffi
+            out = ffi.Position()                     # a single-stage call on the SAME context: writes slot 0's buffer
+            assert hp.lib.oatgpu_detect_hsv(hp.ctx, 0, ffi.u8(np.ascontiguousarray(hsv_probe)), C.byref(out)) == 0
+        r1 = hp.collect()[0]
+        r2 = hp.collect()[0]
+        _same_detection(r1, O.chain_step(orc, busy, 0.01, p)[0], ("busy", use_ready))
+        _same_detection(r2, O.chain_step(orc, calm, 0.01, p)[0], ("calm", use_ready))

@@ -51,6 +51,7 @@ def main():
     orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
     okal = [O.Kalman(**kal) for _ in range(n)]
 
+    hp.set_fusion(2)       # device frames: two frames a launch is opt-in (oatgpu_set_fusion); the pool stays untouched
     order = [(t * 7 + t // args.pool) % args.pool for t in range(args.frames)]
     got = []
     t0 = time.perf_counter()
