@@ -28,11 +28,41 @@
 
 namespace oatgpu {
 
-struct PxModel {
+// The mixture of one pixel in registers.  TUP (r03): a mode's {variance, mean[3]} as ONE ext-vector -- a contiguous
+// register tuple, the shape the 16-byte record loads and stores move: no repacking moves behind a load (and so no
+// `s_waitcnt vmcnt(0)` inside each exec-masked load region: the record loads of a full lane are in flight together),
+// none in front of a store.  Measured (profiles/r03b_k1_ab.txt, same box): everyday 4K model 143 -> 120 us per
+// two-frame launch, 16 x 1080p 558 -> 477 us, one 1080p stream 39.0 -> 34.6 us -- with MORE vector instructions per
+// wave (515 against 504): the kernel is bound by its chain of dependent memory round trips, not by its instruction
+// count.  The streaming-load instantiations (dense models) keep scalar registers: with every lane loading every
+// record, four loads in flight per wave at once ran the dense 4K launch at 324-329 us against 293-295 us.  GREY
+// keeps scalars too (8-byte records; its tuple form is not written).
+template <int CH, bool TUP> struct PxModel;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int CH>
+struct PxModel<CH, false> {
     float w[kMaxMix];
     float v[kMaxMix];
     float m[kMaxMix][3];
 };
+template <>
+struct PxModel<3, true> {
+    float w[kMaxMix];
+    f32x4 r[kMaxMix];            // {variance, mean[0..2]}
+};
+#ifdef OATGPU_NO_TUPLE_RECORDS       // (make variant DEFS=-DOATGPU_NO_TUPLE_RECORDS: the A/B build)
+#define OATGPU_TUP(CH, NTLD) false
+#else
+#define OATGPU_TUP(CH, NTLD) ((CH) == 3 && !(NTLD))
+#endif
+template <int CH> __device__ __forceinline__ float rv(const PxModel<CH, false> &s, int k) { return s.v[k]; }
+template <int CH> __device__ __forceinline__ float rv(const PxModel<CH, true> &s, int k) { return s.r[k][0]; }
+template <int CH> __device__ __forceinline__ void set_rv(PxModel<CH, false> &s, int k, float x) { s.v[k] = x; }
+template <int CH> __device__ __forceinline__ void set_rv(PxModel<CH, true> &s, int k, float x) { s.r[k][0] = x; }
+template <int C, int CH> __device__ __forceinline__ float rm(const PxModel<CH, false> &s, int k) { return C < CH ? s.m[k][C] : 0.f; }
+template <int C, int CH> __device__ __forceinline__ float rm(const PxModel<CH, true> &s, int k) { return s.r[k][1 + C]; }
+template <int C, int CH> __device__ __forceinline__ void set_rm(PxModel<CH, false> &s, int k, float x) { if (C < CH) s.m[k][C] = x; }
+template <int C, int CH> __device__ __forceinline__ void set_rm(PxModel<CH, true> &s, int k, float x) { s.r[k][1 + C] = x; }
 
 // running state of MOG2Invoker's per-pixel mode loop (OpenCV 3.1.0 bgfg_gaussmix2.cpp)
 struct PxLoop {
@@ -42,7 +72,7 @@ struct PxLoop {
 };
 
 template <int CH>
-__device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // exchange modes i and i-1
+__device__ __forceinline__ void swap_up(PxModel<CH, false> &s, int i, unsigned &dvm)   // exchange modes i and i-1
 {
     dvm |= (3u << (i - 1));
     // v_swap_b32 exchanges two VGPRs in one instruction (hipcc writes three moves for a swap through a temporary:
@@ -66,23 +96,35 @@ __device__ __forceinline__ void swap_up(PxModel &s, int i, unsigned &dvm)   // e
     for (int c = 0; c < CH; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
 #endif
 }
+template <int CH>
+__device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &dvm)
+{
+    dvm |= (3u << (i - 1));
+    asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {        // (elements of a register tuple: through temporaries the allocator coalesces)
+        float p = s.r[i][c], q = s.r[i - 1][c];
+        asm volatile("v_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+        s.r[i][c] = p; s.r[i - 1][c] = q;
+    }
+}
 
 // Iteration MODE of the mode loop on a register resident mixture.
 // dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
 // 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
-template <int CH, int MODE>
-__device__ __forceinline__ void mog2_mode(PxModel &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
+template <int CH, int MODE, bool TUP>
+__device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
                                           float alphaT, float alpha1, float prune, unsigned &dvm)
 {
     if (MODE < c.nmodes) {                // nmodes shrinks when a mode is pruned, as in the reference loop
         float weight = alpha1 * s.w[MODE] + prune;
         bool fit_here = false;
         if (!c.fits) {
-            const float var = s.v[MODE];
-            const float d0 = s.m[MODE][0] - x0;
-            const float d1 = CH == 3 ? s.m[MODE][1] - x1 : 0.f;
-            const float d2 = CH == 3 ? s.m[MODE][2] - x2 : 0.f;
+            const float var = rv(s, MODE);
+            const float d0 = rm<0>(s, MODE) - x0;
+            const float d1 = CH == 3 ? rm<1>(s, MODE) - x1 : 0.f;
+            const float d2 = CH == 3 ? rm<2>(s, MODE) - x2 : 0.f;
             const float dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
             if (c.total < P.TB && dist2 < P.Tb * var) c.background = true;
             if (dist2 < P.Tg * var) {
@@ -90,12 +132,12 @@ __device__ __forceinline__ void mog2_mode(PxModel &s, PxLoop &c, float x0, float
                 fit_here = true;
                 weight += alphaT;
                 const float k = alphaT / weight;
-                s.m[MODE][0] -= k * d0;
-                if (CH == 3) { s.m[MODE][1] -= k * d1; s.m[MODE][2] -= k * d2; }
+                set_rm<0>(s, MODE, rm<0>(s, MODE) - k * d0);
+                if (CH == 3) { set_rm<1>(s, MODE, rm<1>(s, MODE) - k * d1); set_rm<2>(s, MODE, rm<2>(s, MODE) - k * d2); }
                 float varnew = var + k * (dist2 - var);
                 varnew = varnew > P.varMin ? varnew : P.varMin;
                 varnew = varnew < P.varMax ? varnew : P.varMax;
-                s.v[MODE] = varnew;
+                set_rv(s, MODE, varnew);
                 dvm |= (1u << MODE);
                 // The reference bubbles the OLD weight up and then stores the new one
                 // into the final slot; carrying the new weight along is the same state.
@@ -124,8 +166,8 @@ __device__ __forceinline__ void mog2_mode(PxModel &s, PxLoop &c, float x0, float
 // nentry: mode count at entry (the reference's nNewModes).  Returns the foreground-mask value
 // {0, shadowVal, 255}; nmodes_out: the count to store; wchg: weights may differ from what was loaded
 // (false only when alpha == 0 and the renormalisation was by exactly 1).
-template <int CH>
-__device__ __forceinline__ int mog2_finish(PxModel &s, PxLoop &c, int nentry, int &nmodes_out, float x0, float x1,
+template <int CH, bool TUP>
+__device__ __forceinline__ int mog2_finish(PxModel<CH, TUP> &s, PxLoop &c, int nentry, int &nmodes_out, float x0, float x1,
                                            float x2, const MogParams &P, float alphaT, float alpha1, unsigned &dvm,
                                            bool &wchg)
 {
@@ -150,9 +192,9 @@ __device__ __forceinline__ int mog2_finish(PxModel &s, PxLoop &c, int nentry, in
             if (i == mode) {
                 dvm |= (1u << i);
                 s.w[i] = first ? 1.f : alphaT;
-                s.v[i] = P.varInit;
-                s.m[i][0] = x0;
-                if (CH == 3) { s.m[i][1] = x1; s.m[i][2] = x2; }
+                set_rv(s, i, P.varInit);
+                set_rm<0>(s, i, x0);
+                if (CH == 3) { set_rm<1>(s, i, x1); set_rm<2>(s, i, x2); }
             }
         }
         bool moving = true;
@@ -175,7 +217,7 @@ __device__ __forceinline__ int mog2_finish(PxModel &s, PxLoop &c, int nentry, in
 #pragma unroll
         for (int mode = 0; mode < kMaxMix; ++mode) {
             if (!done && mode < nmodes) {
-                const float m0 = s.m[mode][0], m1 = CH == 3 ? s.m[mode][1] : 0.f, m2 = CH == 3 ? s.m[mode][2] : 0.f;
+                const float m0 = rm<0>(s, mode), m1 = CH == 3 ? rm<1>(s, mode) : 0.f, m2 = CH == 3 ? rm<2>(s, mode) : 0.f;
                 const float num = CH == 3 ? x0 * m0 + x1 * m1 + x2 * m2 : x0 * m0;
                 const float den = CH == 3 ? m0 * m0 + m1 * m1 + m2 * m2 : m0 * m0;
                 if (den == 0.f) {
@@ -185,7 +227,7 @@ __device__ __forceinline__ int mog2_finish(PxModel &s, PxLoop &c, int nentry, in
                         const float a = num / den;
                         const float e0 = a * m0 - x0, e1 = a * m1 - x1, e2 = a * m2 - x2;
                         const float dist2a = CH == 3 ? e0 * e0 + e1 * e1 + e2 * e2 : e0 * e0;
-                        if (dist2a < P.Tb * s.v[mode] * a * a) { mask = P.shadowVal; done = true; }
+                        if (dist2a < P.Tb * rv(s, mode) * a * a) { mask = P.shadowVal; done = true; }
                     }
                     if (!done) {
                         tW += s.w[mode];
@@ -399,29 +441,35 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // issue even when no lane touches memory (six all-out-of-range loads per wave: +15 us).
     // (NB: __builtin_bit_cast(float, q.y) on a vector ELEMENT reads element 0 in ROCm 7.2's clang -- use
     // __uint_as_float(q.y); that, not the builtin, made the 16-byte buffer load look broken earlier this round.)
-    auto ld_rec = [&](int k, float &v, float *m) {                  // {variance, mean[CH]} of mode k
+    constexpr bool TUP = OATGPU_TUP(CH, NTLD);
+    PxModel<CH, TUP> pm;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto ld_rec = [&](int k) {                                      // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
-        if (CH == 3) {
-            // (round 2 kept this a HIP float4 load because the ext-vector form "broke" the audit instantiation: that was
-            // the register allocation moving and st_rec's wide-store hazard striking, DESIGN.md 3b -- not the load)
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
+        if constexpr (TUP) {
+            pm.r[k] = *(const f32x4 *)rp;
+        } else if constexpr (CH == 3) {
             if (NTLD && k >= 1) {
                 const f32x4 q = __builtin_nontemporal_load((const f32x4 *)rp);
-                v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+                pm.v[k] = q.x; pm.m[k][0] = q.y; pm.m[k][1] = q.z; pm.m[k][2] = q.w;
             } else {
                 const float4 q = *(const float4 *)rp;
-                v = q.x; m[0] = q.y; m[1] = q.z; m[2] = q.w;
+                pm.v[k] = q.x; pm.m[k][0] = q.y; pm.m[k][1] = q.z; pm.m[k][2] = q.w;
             }
         } else {
             const float2 q = *(const float2 *)rp;
-            v = q.x; m[0] = q.y;
+            pm.v[k] = q.x; pm.m[k][0] = q.y;
         }
     };
-    auto st_rec = [&](int k, float v, const float *m) {
-        if (CH == 3) {
+    auto st_rec = [&](int k) {
+        if constexpr (CH == 3) {
             u32x4 q;
-            q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
-            q.z = __builtin_bit_cast(unsigned, m[1]); q.w = __builtin_bit_cast(unsigned, m[2]);
+            if constexpr (TUP) {
+                q = __builtin_bit_cast(u32x4, pm.r[k]);
+            } else {
+                q.x = __builtin_bit_cast(unsigned, pm.v[k]); q.y = __builtin_bit_cast(unsigned, pm.m[k][0]);
+                q.z = __builtin_bit_cast(unsigned, pm.m[k][1]); q.w = __builtin_bit_cast(unsigned, pm.m[k][2]);
+            }
             if (k >= 1) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
             else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
             // gfx950 wide-store data hazard (tools/store_hazard_repro.hip): a store of more than 64
@@ -433,9 +481,15 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             asm volatile("s_nop 1" :: "v"(q));
         } else {
             u32x2 q;
-            q.x = __builtin_bit_cast(unsigned, v); q.y = __builtin_bit_cast(unsigned, m[0]);
+            q.x = __builtin_bit_cast(unsigned, rv(pm, k)); q.y = __builtin_bit_cast(unsigned, rm<0>(pm, k));
             __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, voff_r, SR(k), 0);
         }
+    };
+    auto pin_rec = [&](int k, bool with_w) {       // an empty asm that uses the registers: pins the wait for their loads here
+        if (with_w) asm volatile("" : "+v"(pm.w[k]));
+        if constexpr (TUP) asm volatile("" : "+v"(pm.r[k]));
+        else if constexpr (CH == 3) asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
+        else asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]));
     };
     uint8_t *nmbase = a.nmodes + (size_t)s * g.Palloc;
     const unsigned coff = p;
@@ -449,16 +503,22 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 #define AU_B(m, wr) au.byte((m), (wr))
 
     // ---- phase 1: counter byte, mode 0, the pixel -- for every lane, nothing depends on anything ----
-    PxModel pm;
+    // Everything starts at 0: a slot that is not loaded is dead, and its weight 0 takes part in the arithmetic.
+    // (Leaving the {variance, mean} registers of slots >= 1 undefined instead -- read only by lanes that loaded or wrote
+    // them -- saves 16 v_mov a launch but cost the two-frame BGR instantiation 16 bytes of scratch at 64 registers and
+    // 14 % of its speed: measured and not adopted, profiles/r03b_k1_ab.txt.)
 #pragma unroll
-    for (int k = 0; k < kMaxMix; ++k) { pm.w[k] = 0.f; pm.v[k] = 0.f; pm.m[k][0] = 0.f; pm.m[k][1] = 0.f; pm.m[k][2] = 0.f; }
+    for (int k = 0; k < kMaxMix; ++k) {
+        pm.w[k] = 0.f;
+        set_rv(pm, k, 0.f); set_rm<0>(pm, k, 0.f); set_rm<1>(pm, k, 0.f); set_rm<2>(pm, k, 0.f);
+    }
     int cnt = 0;
     int b = 0, gg = 0, r = 0;
     // (no `active` guard: the planes are allocated for Palloc pixels, a multiple of the block's 256)
     if (!a.fresh) {
         cnt = nmbase[coff];
         pm.w[0] = LDW(0);
-        ld_rec(0, pm.v[0], pm.m[0]);
+        ld_rec(0);
         AU_B(active, false);
         AU_DW(active, false);
         AU_REC(active, false);
@@ -492,7 +552,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     PxLoop lp{false, false, nold, 0.f};
     unsigned dvm = 0;           // modes whose variance/mean changed
     bool wchg = false;          // weights changed
-    if (valid) mog2_mode<CH, 0>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+    if (valid) mog2_mode<CH, 0, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
     // A pixel that matched mode 0 as background never looks at another mode's variance/mean again this
     // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
     // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
@@ -507,7 +567,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             const bool have = valid && k < nold;
             const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
             if (lw) pm.w[k] = LDW(k);
-            if (have && full) ld_rec(k, pm.v[k], pm.m[k]);
+            if (have && full) ld_rec(k);
             AU_DW(lw, false);
             AU_REC(have && full, false);
         }
@@ -519,15 +579,18 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // had more than four stores in flight.
 #pragma unroll
     for (int k = 1; k < kMaxMix; ++k)
-        asm volatile("" : "+v"(pm.w[k]), "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
+        pin_rec(k, true);
 
+    // (r03, measured and rejected: skipping iteration k >= 1 on lanes that have fitted and hold no live slot at k or
+    // behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already ends the walk two dead
+    // slots in, and the guards cost more vector instructions than they save, profiles/r03b_k1_ab.txt.)
     int mask = 0, nnew = nold;
     if (work) {
-        mog2_mode<CH, 1>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 2>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 3>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 4>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mask = mog2_finish<CH>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg);
+        mog2_mode<CH, 1, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 2, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 3, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 4, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mask = mog2_finish<CH, TUP>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg);
     }
 
     // frame.setTo(0, mask == 0): shadows (127) stay foreground
@@ -564,25 +627,25 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
         PxLoop lq{false, false, nold2, 0.f};
         bool wchg2 = false;
-        if (valid) mog2_mode<CH, 0>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+        if (valid) mog2_mode<CH, 0, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
         const bool full2 = valid && !(lq.fits && lq.background);
         // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
         const bool need2 = full2 && !full;
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k) {
-            if (need2 && k < nold2) ld_rec(k, pm.v[k], pm.m[k]);
+            if (need2 && k < nold2) ld_rec(k);
             AU_REC(need2 && k < nold2, false);
         }
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k)
-            asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]), "+v"(pm.m[k][1]), "+v"(pm.m[k][2]));
+            pin_rec(k, false);
         int mask2 = 0, nnew2 = nold2;
         if (work) {
-            mog2_mode<CH, 1>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 2>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 3>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 4>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mask2 = mog2_finish<CH>(pm, lq, nold2, nnew2, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, dvm, wchg2);
+            mog2_mode<CH, 1, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 2, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 3, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mog2_mode<CH, 4, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, dvm, wchg2);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
         if (CH == 3) {
@@ -610,7 +673,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         const bool was_live = k == 0 || full_any || ((cnt >> (kLiveShift + k)) & 1);
         const bool sw = work && wchg && k < nlive && was_live, svm = (dvm >> k) & 1u;
         if (sw) STW(k, pm.w[k]);
-        if (svm) st_rec(k, pm.v[k], pm.m[k]);
+        if (svm) st_rec(k);
         AU_DW(sw, true);
         AU_REC(svm, true);
         if (k >= 1 && k < nnew && __float_as_uint(pm.w[k]) != 0u) newcnt |= 1 << (kLiveShift + k);   // (bits: an imported -0.f is live)
