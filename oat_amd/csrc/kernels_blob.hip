@@ -608,7 +608,16 @@ __global__ __launch_bounds__(kGreenBlock) void k_green_select(Geom g, BlobBuffer
 //   (8-connected: overlap widened by one pixel).
 // Falls back (lds_ok = 0: k_merge + k_green_select take the frame) when the frame has more than kLdsRows dirty rows,
 // kLdsRuns runs or kLdsRoots foreground components.
-constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768, kLdsBlock = 1024;      // 58 KB of LDS
+constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768;      // 58 KB of LDS
+#ifndef OATGPU_LDS_BLOCK
+#define OATGPU_LDS_BLOCK 1024
+#endif
+// Threads of the one workgroup.  r03 (profiles/r03c_backhalf_under_load.txt): beside the per-pixel kernel this kernel takes
+// 93-96 us at 4K against 21-23 us alone -- not because it waits for a compute unit with 16 free wave slots (rocprof's
+// duration is execution time; 512 / 256 threads, which fit a partly occupied unit, ran 106 / 111 us and cost the one-
+// 1080p-stream workload 16-21 % of its frame rate) and not for want of issue slots (s_setprio 3: no change): its ~15
+// dependent global round trips queue behind the per-pixel kernel's saturated memory system.
+constexpr int kLdsBlock = OATGPU_LDS_BLOCK;
 
 __device__ __forceinline__ int lds_find(int *par, int i)
 {
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     __shared__ unsigned short rootslot[kLdsRuns + 2];
     __shared__ int rootnode[kLdsRoots];
     __shared__ unsigned long long acc[kLdsRoots * 3];
-    __shared__ unsigned scan_d[16], scan_r[16];
+    __shared__ unsigned scan_d[kLdsBlock / 64], scan_r[kLdsBlock / 64];
     __shared__ unsigned nroots_s;
     __shared__ unsigned short fglist[kLdsRuns / 2 + 2];  // the foreground nodes, in any order (phase E walks these)
     __shared__ unsigned long long red[kLdsBlock / 64];

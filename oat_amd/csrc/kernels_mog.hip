@@ -567,9 +567,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             const bool have = valid && k < nold;
             const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
             if (lw) pm.w[k] = LDW(k);
-            if (have && full) ld_rec(k);
+            const bool lr = have && full;
+            if (lr) ld_rec(k);
             AU_DW(lw, false);
-            AU_REC(have && full, false);
+            AU_REC(lr, false);
         }
     }
 
@@ -581,9 +582,11 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     for (int k = 1; k < kMaxMix; ++k)
         pin_rec(k, true);
 
-    // (r03, measured and rejected: skipping iteration k >= 1 on lanes that have fitted and hold no live slot at k or
-    // behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already ends the walk two dead
-    // slots in, and the guards cost more vector instructions than they save, profiles/r03b_k1_ab.txt.)
+    // (r03, measured and rejected, profiles/r03b_k1_ab.txt: (i) skipping iteration k >= 1 on lanes that have fitted and
+    // hold no live slot at k or behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already
+    // ends the walk two dead slots in, and the guards cost more vector instructions than they save; (ii) loading the
+    // record of a live slot 1 also on lanes that matched, so that frame 2 seldom needs a round trip of its own: 122.1
+    // against 121.8 us.)
     int mask = 0, nnew = nold;
     if (work) {
         mog2_mode<CH, 1, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
@@ -633,8 +636,9 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         const bool need2 = full2 && !full;
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k) {
-            if (need2 && k < nold2) ld_rec(k);
-            AU_REC(need2 && k < nold2, false);
+            const bool l2 = need2 && k < nold2;
+            if (l2) ld_rec(k);
+            AU_REC(l2, false);
         }
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k)
