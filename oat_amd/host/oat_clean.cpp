@@ -6,7 +6,7 @@ int main(int argc, char **argv)
 {
     for (int i = 1; i < argc; ++i) {
         std::string n = argv[i];
-        bool a = oat::detail::Segment::remove(n + "_node"), b = oat::detail::Segment::remove(n + "_obj");
+        bool a = oat::remove_segment(n + "_node"), b = oat::remove_segment(n + "_obj");
         printf("%s: %s\n", argv[i], (a || b) ? "removed" : "nothing to remove");
     }
     return 0;

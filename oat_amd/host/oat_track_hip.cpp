@@ -21,11 +21,18 @@
 // kernels of step t, GPU-bound pipelines).  Options are the union of the three stock components'
 // (-a is mog's adaptation coefficient; the detector's area is --area).
 //
+// --gpu-index D0,D1,...  shards the cameras over several devices from THIS process (BASELINE configs 3/4 at the
+// drop-in boundary: 64 x 1080p as 8 per GPU, 8 x 4K as one per GPU): the SOURCE list is cut into
+// contiguous blocks -- camera s goes to shard s / ceil(S/N), as oat_amd/dist.py partitions streams over ranks --
+// and every shard is a batched tracker of its own (own device context, own thread, own loop): streams are
+// independent, so nothing crosses between shards.  The same device may be named twice (two contexts on one GPU).
+//
 // --thresh [lo,hi] selects the GREY chain instead:  framefilt mog -> posidet thresh  on SOURCEs that carry GREY
 // frames (a mono camera or `framefilt col -C GREY`; SimpleThreshold.cpp:46 requires them), the one-channel model
 // and the intensity window of SimpleThreshold.cpp:171-174 in the same fused launches.
 #include "component.hpp"
 #include <deque>
+#include <thread>
 #include <unistd.h>
 
 using namespace oat;
@@ -47,8 +54,11 @@ static std::vector<std::string> split_list(const std::string &s)
 
 class BatchedTracker : public Component {
 public:
-    BatchedTracker(const std::vector<std::string> &sources, const std::vector<std::string> &sinks)
-        : source_addresses_(sources), sink_addresses_(sinks), n_((int)sources.size())
+    // stream_base / n_total: where this shard's cameras sit in the command line's SOURCE list (model file names)
+    BatchedTracker(const std::vector<std::string> &sources, const std::vector<std::string> &sinks, int stream_base = 0,
+                   int n_total = -1)
+        : source_addresses_(sources), sink_addresses_(sinks), n_((int)sources.size()), stream_base_(stream_base),
+          n_total_(n_total < 0 ? (int)sources.size() : n_total)
     {
         if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
         oatgpu_default_config(&cfg_);
@@ -76,7 +86,7 @@ public:
     }
 
 protected:
-    std::string model_path(int s) const { return n_ == 1 ? model_file_ : model_file_ + "." + std::to_string(s); }
+    std::string model_path(int s) const { return n_total_ == 1 ? model_file_ : model_file_ + "." + std::to_string(stream_base_ + s); }
 
     // PositionDetector.cpp:40-56, for every stream
     bool connectToNode() override
@@ -175,7 +185,7 @@ protected:
 
     std::string name_;
     std::vector<std::string> source_addresses_, sink_addresses_;
-    int n_;
+    int n_, stream_base_, n_total_;
     std::vector<Source<Frame>> frame_sources_;
     std::vector<Sink<Position2D>> position_sinks_;
     std::vector<Position2D *> shared_positions_;
@@ -196,40 +206,66 @@ int main(int argc, char **argv)
         if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
-                         "       [--gpu-index N] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
+                         "       [--gpu-index N | N0,N1,..] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
                          "       [--thresh [lo,hi]]   GREY SOURCEs: framefilt mog -> posidet thresh instead of the HSV chain\n"
                          "       [--homography [h11,h12,...,h33]]   posifilt homography fused in (positions in world units)\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
-                         "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n";
+                         "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n"
+                         "--gpu-index N0,N1,..: the cameras are split into contiguous blocks, one per listed device (own context and thread).\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
                         "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography"}, {"kalman"});
-        auto t = std::make_unique<BatchedTracker>(split_list(o.positional[0]), split_list(o.positional[1]));
-        t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
-        double a, b;
-        if (o.arr2("h-thresh", a, b)) { t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b; }
-        if (o.arr2("s-thresh", a, b)) { t->cfg_.s_lo = (int)a; t->cfg_.s_hi = (int)b; }
-        if (o.arr2("v-thresh", a, b)) { t->cfg_.v_lo = (int)a; t->cfg_.v_hi = (int)b; }
-        if (o.arr2("thresh", a, b)) {                                 // SimpleThreshold.cpp:86-97
-            if (a < 0 || a > 256 || b < 0 || b > 256) throw std::runtime_error("Values of thresh should be between 0 and 256.");
-            t->grey_ = true;
-            t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b;              // the one-channel window lives in the h slot
+        const std::vector<std::string> sources = split_list(o.positional[0]), sinks = split_list(o.positional[1]);
+        if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
+        // --gpu-index N | N0,N1,...: one shard of the SOURCE list per listed device (contiguous blocks)
+        std::vector<int> devices;
+        for (const std::string &d : split_list(o.has("gpu-index") ? o.kv["gpu-index"] : std::string("0"))) {
+            char *end = nullptr;
+            const long v = strtol(d.c_str(), &end, 10);
+            if (!end || *end || v < 0 || v > 1023) throw std::runtime_error("--gpu-index: expected N or N0,N1,... (device ordinals)");
+            devices.push_back((int)v);
         }
-        if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
-        if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
-        if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }
-        t->cfg_.device = (int)o.num("gpu-index", 0, 0, 64);
-        t->cfg_.ring_depth = (int)o.num("ring", 2, 1, 64);
-        if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
-        if (o.has("mask")) t->mask_file_ = o.kv["mask"];
-        t->kalman_ = o.has("kalman");
-        t->homography_on_ = o.arr9("homography", t->homography_);
-        t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)
-        t->timeout_ = o.num("timeout", 0.0, 0, 1e18);
-        t->sig_accel_ = o.num("sigma-accel", 5.0, 0, 1e18);
-        t->sig_noise_ = o.num("sigma-noise", 0.0, 0, 1e18);
-        return t->run();
+        const int S = (int)sources.size(), N = (int)devices.size(), per = (S + N - 1) / N;
+        std::vector<std::unique_ptr<BatchedTracker>> shards;
+        for (int k = 0; k < N && k * per < S; ++k) {
+            const int s0 = k * per, s1 = std::min(S, s0 + per);
+            auto t = std::make_unique<BatchedTracker>(std::vector<std::string>(sources.begin() + s0, sources.begin() + s1),
+                                                      std::vector<std::string>(sinks.begin() + s0, sinks.begin() + s1), s0, S);
+            t->learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
+            double a, b;
+            if (o.arr2("h-thresh", a, b)) { t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b; }
+            if (o.arr2("s-thresh", a, b)) { t->cfg_.s_lo = (int)a; t->cfg_.s_hi = (int)b; }
+            if (o.arr2("v-thresh", a, b)) { t->cfg_.v_lo = (int)a; t->cfg_.v_hi = (int)b; }
+            if (o.arr2("thresh", a, b)) {                                 // SimpleThreshold.cpp:86-97
+                if (a < 0 || a > 256 || b < 0 || b > 256) throw std::runtime_error("Values of thresh should be between 0 and 256.");
+                t->grey_ = true;
+                t->cfg_.h_lo = (int)a; t->cfg_.h_hi = (int)b;              // the one-channel window lives in the h slot
+            }
+            if (o.has("erode")) t->cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
+            if (o.has("dilate")) t->cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
+            if (o.arr2("area", a, b)) { t->cfg_.min_area = a; t->cfg_.max_area = b; }
+            t->cfg_.device = devices[k];
+            t->cfg_.ring_depth = (int)o.num("ring", 2, 1, 64);
+            if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
+            if (o.has("mask")) t->mask_file_ = o.kv["mask"];
+            t->kalman_ = o.has("kalman");
+            t->homography_on_ = o.arr9("homography", t->homography_);
+            t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)
+            t->timeout_ = o.num("timeout", 0.0, 0, 1e18);
+            t->sig_accel_ = o.num("sigma-accel", 5.0, 0, 1e18);
+            t->sig_noise_ = o.num("sigma-noise", 0.0, 0, 1e18);
+            shards.push_back(std::move(t));
+        }
+        if (shards.size() == 1) return shards[0]->run();
+        // one thread per shard: a device context belongs to the thread that drives it; SIGINT reaches every loop
+        // through `quit` (the waits are 10 ms slices), END of a shard's SOURCEs ends that shard only
+        std::vector<int> rc(shards.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < shards.size(); ++k) th.emplace_back([&, k] { rc[k] = shards[k]->run(); });
+        for (auto &t : th) t.join();
+        for (int r : rc) if (r) return r;
+        return 0;
     } catch (const std::exception &e) {
         std::cerr << "oat-track-hip: " << e.what() << std::endl;
         return -1;

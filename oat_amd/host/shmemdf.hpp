@@ -231,6 +231,8 @@ private:
     sem_t rb_[NUM_SLOTS];
 };
 
+inline bool remove_segment(const std::string &name) { return detail::Segment::remove(name); }
+
 }  // namespace native
 
 namespace detail {
@@ -289,6 +291,7 @@ public:
         node_->notifySinkWriteComplete();
         did_wait_need_post_ = false;
     }
+    size_t source_ref_count() const { return node_->source_ref_count(); }   // SOURCEs attached to this node (Node.h:139)
     uint64_t write_number() const { return node_->write_number(); }
 
 protected:

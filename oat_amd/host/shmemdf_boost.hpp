@@ -15,9 +15,10 @@
 //   lib/shmemdf/SharedFrameHeader.h:91-96            params_, data_, sample_ (oat::SharedFrameHeader of
 //                                                    datatypes.hpp has that layout, static_asserted)
 //
-// Compile-guarded: this image (and the GPU box) has no Boost, so the header is inert here -- the Makefile
-// probes for <boost/interprocess/managed_shared_memory.hpp> and defines OAT_SHMEM_BOOST only where it
-// exists; shmemdf.hpp then selects oat::stock instead of oat::native.  The object NAMES are the
+// Compile-guarded AND opt-in: this image (and the GPU box) has no Boost, so the header is inert here; where
+// Boost exists, `make -C oat_amd/host SHMEM=boost` defines OAT_SHMEM_BOOST and shmemdf.hpp then selects
+// oat::stock instead of oat::native (`make boostcheck` builds and runs the protocol tests on it first).  It has
+// never been run against a stock oat-* process: until it has, the native transport is what the binaries use.  The object NAMES are the
 // Itanium-mangled type names typeid(T).name() yields for the reference's own classes with GCC/Clang,
 // spelled out because this tree's classes live in other namespaces.
 #pragma once
@@ -27,6 +28,43 @@
 #define OAT_HAVE_BOOST_INTERPROCESS 1
 #endif
 #endif
+
+// ---- layout self-check (compiled everywhere, Boost or not) ----
+// The reference's Node (lib/shmemdf/Node.h:170-183, with `write_barrier` declared in front of the private members,
+// :143) as a plain aggregate over an arbitrary semaphore type: what offsets and size its member order implies.
+// With glibc's 32-byte sem_t -- what boost::interprocess::interprocess_semaphore wraps on Linux
+// (BOOST_INTERPROCESS_POSIX_SEMAPHORES) -- that is write_barrier 0, sink_state_ 32, source_slots_ 40,
+// source_read_required_ 48, source_ref_count_ 56, write_number_ 64, mutex_ 72, rb0_.. 104 + 32 i, 424 bytes: the
+// "<addr>_node" segment of Sink.h:171-176 is 1024 + 424 bytes.  stock::Node below is asserted against this twin
+// instantiated with Boost's own semaphore type, member by member.
+#include <atomic>
+#include <bitset>
+#include <cstddef>
+#include <cstdint>
+#include <semaphore.h>
+
+namespace oat {
+namespace stock_layout {
+template <typename Sem>
+struct NodeTwin {
+    Sem write_barrier;
+    std::atomic<int> sink_state_;
+    std::bitset<10> source_slots_, source_read_required_;
+    size_t source_ref_count_;
+    uint64_t write_number_;
+    Sem mutex_;
+    Sem rb_[10];
+};
+#if defined(__linux__) && defined(__x86_64__)
+static_assert(sizeof(sem_t) == 32 && sizeof(std::bitset<10>) == 8, "glibc x86-64 sem_t / libstdc++ bitset sizes");
+static_assert(offsetof(NodeTwin<sem_t>, sink_state_) == 32 && offsetof(NodeTwin<sem_t>, source_slots_) == 40 &&
+              offsetof(NodeTwin<sem_t>, source_read_required_) == 48 && offsetof(NodeTwin<sem_t>, source_ref_count_) == 56 &&
+              offsetof(NodeTwin<sem_t>, write_number_) == 64 && offsetof(NodeTwin<sem_t>, mutex_) == 72 &&
+              offsetof(NodeTwin<sem_t>, rb_) == 104 && sizeof(NodeTwin<sem_t>) == 424,
+              "layout implied by lib/shmemdf/Node.h:143,170-183");
+#endif
+}  // namespace stock_layout
+}  // namespace oat
 
 #if defined(OAT_HAVE_BOOST_INTERPROCESS)
 
@@ -46,6 +84,8 @@ constexpr const char *kNodeName = "N3oat4NodeE";                       // typeid
 template <typename T> struct StockName;
 template <> struct StockName<Position2D> { static const char *get() { return "N3oat10Position2DE"; } };
 template <> struct StockName<SharedFrameHeader> { static const char *get() { return "N3oat17SharedFrameHeaderE"; } };
+template <> struct StockName<int> { static const char *get() { return "i"; } };       // (the protocol tests: Sink<int>, Source<float>,
+template <> struct StockName<float> { static const char *get() { return "f"; } };     //  as the reference's own Sink_test / Source_test)
 
 // lib/shmemdf/Node.h:41-184 -- same members, same order, same types: this IS the object stock binaries
 // find under kNodeName.  (The reference's read_barrier() switch lacks `case 5`; slot 5 works here.)
@@ -119,7 +159,26 @@ private:
     uint64_t write_number_{0};
     semaphore mutex_{1};
     semaphore rb0_{0}, rb1_{0}, rb2_{0}, rb3_{0}, rb4_{0}, rb5_{0}, rb6_{0}, rb7_{0}, rb8_{0}, rb9_{0};
+    friend struct NodeLayoutCheck;
 };
+
+// stock::Node member by member against the reference's layout (stock_layout::NodeTwin over Boost's semaphore type)
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+struct NodeLayoutCheck {
+    using Twin = stock_layout::NodeTwin<Node::semaphore>;
+    static_assert(sizeof(Node) == sizeof(Twin) && alignof(Node) == alignof(Twin), "stock::Node size");
+    static_assert(offsetof(Node, write_barrier) == offsetof(Twin, write_barrier), "write_barrier");
+    static_assert(offsetof(Node, sink_state_) == offsetof(Twin, sink_state_), "sink_state_");
+    static_assert(offsetof(Node, source_slots_) == offsetof(Twin, source_slots_), "source_slots_");
+    static_assert(offsetof(Node, source_read_required_) == offsetof(Twin, source_read_required_), "source_read_required_");
+    static_assert(offsetof(Node, source_ref_count_) == offsetof(Twin, source_ref_count_), "source_ref_count_");
+    static_assert(offsetof(Node, write_number_) == offsetof(Twin, write_number_), "write_number_");
+    static_assert(offsetof(Node, mutex_) == offsetof(Twin, mutex_), "mutex_");
+    static_assert(offsetof(Node, rb0_) == offsetof(Twin, rb_) && offsetof(Node, rb9_) == offsetof(Twin, rb_) + 9 * sizeof(Node::semaphore), "read barriers");
+    static_assert(sizeof(NodeState) == sizeof(int), "NodeState is an int-sized enum in the reference");
+};
+#pragma GCC diagnostic pop
 
 inline bool timed_wait_10ms(bip::interprocess_semaphore &s)
 {
@@ -157,6 +216,7 @@ public:
         node_->notifySinkWriteComplete();
         did_wait_need_post_ = false;
     }
+    size_t source_ref_count() const { return node_->source_ref_count(); }   // SOURCEs attached to this node (Node.h:139)
     uint64_t write_number() const { return node_->write_number(); }
 
 protected:

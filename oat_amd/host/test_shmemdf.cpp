@@ -26,14 +26,18 @@ static int g_fail = 0, g_checks = 0;
 #define CHECK_NOTHROW(expr) do { ++g_checks; try { expr; } catch (const std::exception &e) { ++g_fail; printf("FAIL %s:%d  threw %s: %s\n", __FILE__, __LINE__, e.what(), #expr); } } while (0)
 
 static std::string ADDR;
-static void scrub() { detail::Segment::remove(ADDR + "_node"); detail::Segment::remove(ADDR + "_obj"); }
+static void scrub() { remove_segment(ADDR + "_node"); remove_segment(ADDR + "_obj"); }
 template <typename F> static bool ready(F &f, std::chrono::milliseconds d = 5ms) { return f.wait_for(d) == std::future_status::ready; }
 
 static void node_tests()
 {
     // Node_test.cpp:28-78
+#if defined(OAT_SHMEM_BOOST)
+    Node *n = new Node();                              // (stock Oat's Node is constructed in place by Boost; here on the heap)
+#else
     Node *n = (Node *)aligned_alloc(64, (sizeof(Node) + 127) / 64 * 64);
     n->construct();
+#endif
     size_t idx = 0;
     for (size_t i = 0; i < Node::NUM_SLOTS; ++i) { CHECK(n->acquireSlot(idx) == 0); CHECK(idx == i); }
     CHECK(n->acquireSlot(idx) == -1);                 // the 11th fails
@@ -46,7 +50,11 @@ static void node_tests()
     CHECK_THROWS(n->read_barrier((size_t)-1));
     CHECK(n->acquireSlot(idx) == 0 && idx == 0);
     CHECK_THROWS(n->read_barrier(1));                 // not bound to that slot
+#if defined(OAT_SHMEM_BOOST)
+    delete n;
+#else
     free(n);
+#endif
 }
 
 static void sink_tests()

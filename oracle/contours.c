@@ -488,18 +488,15 @@ static void *chain_worker(void *arg)
 static void chain_parallel(chain_job proto, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
+    if (nthreads > 512) nthreads = 512;
     if (nthreads > proto.rows) nthreads = proto.rows;
-    pthread_t th[256];
-    chain_job jobs[256];
+    chain_job jobs[512];
     for (int t = 0; t < nthreads; t++) {
         jobs[t] = proto;
         jobs[t].y0 = (int)((long)proto.rows * t / nthreads);
         jobs[t].y1 = (int)((long)proto.rows * (t + 1) / nthreads);
-        if (nthreads == 1) { chain_worker(&jobs[0]); return; }
-        pthread_create(&th[t], NULL, chain_worker, &jobs[t]);
     }
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    oat_pool_run(chain_worker, jobs, sizeof jobs[0], nthreads);    /* persistent workers (pool.c) */
 }
 
 static void morph_mt(uint8_t *img, uint8_t *tmp, int rows, int cols, int k, int is_erode, int nthreads)
@@ -515,13 +512,21 @@ void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double lear
                     const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
                     oat_detection *out, int nthreads)
 {
+    oat_chain_step_from(m, NULL, frame, rows, cols, learning_rate, p, scratch, thr_out, out, nthreads);
+}
+
+/* src != NULL: the caller's frame stays untouched; `work` (rows*cols*channels bytes) receives the filtered copy */
+void oat_chain_step_from(oat_mog2 *m, const uint8_t *src, uint8_t *work, int rows, int cols, double learning_rate,
+                         const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
+                         oat_detection *out, int nthreads)
+{
     size_t n = (size_t)rows * cols;
     uint8_t *mask = scratch;            /* n   (reused as the morphology temporary) */
     uint8_t *hsv = scratch + n;         /* 3n  */
     uint8_t *thr = scratch + 4 * n;     /* n   */
-    oat_mog2_filter_mt(m, frame, mask, learning_rate, nthreads);
+    oat_mog2_filter_from(m, src, work, mask, learning_rate, nthreads);
     int lo[3] = { p->h_lo, p->s_lo, p->v_lo }, hi[3] = { p->h_hi, p->s_hi, p->v_hi };
-    chain_job j = { 0, frame, thr, hsv, rows, cols, oat_mog2_channels(m), 0, 0, 0, lo, hi };   /* k carries the channel count for stage 0 */
+    chain_job j = { 0, work, thr, hsv, rows, cols, oat_mog2_channels(m), 0, 0, 0, lo, hi };   /* k carries the channel count for stage 0 */
     chain_parallel(j, nthreads);
     if (p->erode > 0) morph_mt(thr, mask, rows, cols, p->erode, 1, nthreads);
     if (p->dilate > 0) morph_mt(thr, mask, rows, cols, p->dilate, 0, nthreads);

@@ -42,6 +42,7 @@ struct oat_mog2 {
     gmm_t *gmm;          /* rows*cols*nmixtures, AoS like OpenCV's bgmodel      */
     float *mean;         /* rows*cols*nmixtures*ch                              */
     uint8_t *modes_used; /* rows*cols                                           */
+    int pristine;        /* arrays still as calloc left them: all zero, pages not yet touched */
 };
 
 void oat_mog2_default_params(oat_mog2_params *p)
@@ -77,6 +78,7 @@ oat_mog2 *oat_mog2_create(int rows, int cols, int channels, const oat_mog2_param
     m->mean = (float *)calloc(n * m->p.nmixtures * channels, sizeof(float));
     m->modes_used = (uint8_t *)calloc(n, 1);
     m->nframes = 0;
+    m->pristine = 1;
     return m;
 }
 
@@ -113,6 +115,7 @@ void oat_mog2_set_state(oat_mog2 *m, const uint8_t *modes_used, const float *wei
     }
     memcpy(m->mean, mean, n * m->ch * sizeof(float));
     m->nframes = nframes;
+    m->pristine = 0;
 }
 
 /* detectShadowGMM (bgfg_gaussmix2.cpp) */
@@ -284,12 +287,17 @@ static void mog2_begin(oat_mog2 *m, double learningRate, float *alphaT, float *p
 {
     int needToInitialize = m->nframes == 0 || learningRate >= 1;
     if (needToInitialize) {
-        size_t n = (size_t)m->rows * m->cols;
-        memset(m->gmm, 0, n * m->p.nmixtures * sizeof(gmm_t));
-        memset(m->mean, 0, n * m->p.nmixtures * m->ch * sizeof(float));
-        memset(m->modes_used, 0, n);
+        /* (a model fresh from calloc is zero already; leaving its pages untouched lets the row workers of the first
+         * frame fault them in on their own NUMA nodes -- what a tuned CPU implementation would arrange) */
+        if (!m->pristine) {
+            size_t n = (size_t)m->rows * m->cols;
+            memset(m->gmm, 0, n * m->p.nmixtures * sizeof(gmm_t));
+            memset(m->mean, 0, n * m->p.nmixtures * m->ch * sizeof(float));
+            memset(m->modes_used, 0, n);
+        }
         m->nframes = 0;
     }
+    m->pristine = 0;
     ++m->nframes;
     int lim = 2 * m->nframes < m->p.history ? 2 * m->nframes : m->p.history;
     learningRate = (learningRate >= 0 && m->nframes > 1) ? learningRate : 1. / lim;
@@ -319,11 +327,16 @@ void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning
 
 typedef struct {
     oat_mog2 *m; uint8_t *frame; uint8_t *mask; float alphaT, prune; int y0, y1;
+    const uint8_t *copy_from;      /* not NULL: the caller's (read-only) frame; the worker copies its rows into `frame` first */
 } mog2_job;
 
 static void *mog2_worker(void *arg)
 {
     mog2_job *j = (mog2_job *)arg;
+    if (j->copy_from) {
+        size_t o = (size_t)j->y0 * j->m->cols * j->m->ch, nb = (size_t)(j->y1 - j->y0) * j->m->cols * j->m->ch;
+        memcpy(j->frame + o, j->copy_from + o, nb);
+    }
     mog2_rows(j->m, j->frame, j->mask, j->alphaT, j->prune, j->y0, j->y1);
     size_t off = (size_t)j->y0 * j->m->cols;
     set_to_zero_where_mask0(j->frame + off * j->m->ch, j->mask + off,
@@ -333,19 +346,29 @@ static void *mog2_worker(void *arg)
 
 void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learningRate, int nthreads)
 {
-    if (nthreads <= 1) { oat_mog2_filter(m, frame, mask, learningRate); return; }
-    if (nthreads > 256) nthreads = 256;
+    oat_mog2_filter_from(m, NULL, frame, mask, learningRate, nthreads);
+}
+
+/* The same with the input left untouched: `src` (may be NULL = filter `frame` in place) is copied into `frame` row block
+ * by row block inside the workers (FrameFilter::process copies the shared frame before it filters it, FrameFilter.cpp:73-80) */
+void oat_mog2_filter_from(oat_mog2 *m, const uint8_t *src, uint8_t *frame, uint8_t *mask, double learningRate, int nthreads)
+{
+    if (nthreads <= 1) {
+        if (src) memcpy(frame, src, (size_t)m->rows * m->cols * m->ch);
+        oat_mog2_filter(m, frame, mask, learningRate);
+        return;
+    }
+    if (nthreads > 512) nthreads = 512;
+    if (nthreads > m->rows) nthreads = m->rows;
     float alphaT, prune;
     mog2_begin(m, learningRate, &alphaT, &prune);
-    pthread_t th[256];
-    mog2_job jobs[256];
+    mog2_job jobs[512];
     int rows = m->rows;
     for (int t = 0; t < nthreads; t++) {
         jobs[t].m = m; jobs[t].frame = frame; jobs[t].mask = mask;
-        jobs[t].alphaT = alphaT; jobs[t].prune = prune;
+        jobs[t].alphaT = alphaT; jobs[t].prune = prune; jobs[t].copy_from = src;
         jobs[t].y0 = (int)((long)rows * t / nthreads);
         jobs[t].y1 = (int)((long)rows * (t + 1) / nthreads);
-        pthread_create(&th[t], NULL, mog2_worker, &jobs[t]);
     }
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    oat_pool_run(mog2_worker, jobs, sizeof jobs[0], nthreads);     /* persistent workers (pool.c) */
 }

@@ -70,6 +70,11 @@ void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning
 /* row-parallel variant of oat_mog2_filter (what OpenCV's parallel_for_ does);
  * results identical, rows are independent. */
 void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
+void oat_mog2_filter_from(oat_mog2 *m, const uint8_t *src, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
+
+/* pool.c: persistent workers for the row-parallel stages (created on first use, woken per stage) */
+void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs);
+int oat_pool_max(void);
 
 /* State inspection (tests / parity): per pixel, `nmixtures` entries. */
 void oat_mog2_set_state(oat_mog2 *m, const uint8_t *modes_used, const float *weight, const float *variance,
@@ -213,6 +218,10 @@ void oat_detect_thresh(const uint8_t *grey, int rows, int cols, const oat_hsv_pa
 void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double learning_rate,
                     const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
                     oat_detection *out, int nthreads);
+/* the same on a read-only input: src is copied into work (rows*cols*channels bytes) inside the row workers */
+void oat_chain_step_from(oat_mog2 *m, const uint8_t *src, uint8_t *work, int rows, int cols, double learning_rate,
+                         const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
+                         oat_detection *out, int nthreads);
 
 /* ------------------------------------------------- posifilt kalman -------- */
 

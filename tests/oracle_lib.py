@@ -85,6 +85,8 @@ def _load():
     lib.oat_hsv_default_params.argtypes = [C.POINTER(HsvParams)]
     lib.oat_detect_hsv.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(HsvParams), u8p, C.POINTER(Detection)]
     lib.oat_detect_thresh.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(HsvParams), u8p, C.POINTER(Detection)]
+    lib.oat_chain_step_from.argtypes = [C.c_void_p, u8p, u8p, C.c_int, C.c_int, C.c_double, C.POINTER(HsvParams),
+                                        u8p, u8p, C.POINTER(Detection), C.c_int]
     lib.oat_chain_step.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_double, C.POINTER(HsvParams),
                                    u8p, u8p, C.POINTER(Detection), C.c_int]
     lib.oat_bsub_create.restype = C.c_void_p
@@ -260,13 +262,17 @@ def detect_thresh(grey, p):
 
 def chain_step(mog, frame, lr, p, nthreads=1):
     """mog filter -> (bgr2hsv ->) detect on one frame (frame is not modified); GREY when mog.ch == 1."""
-    frame = _c(frame).copy()
+    frame = _c(frame)
     n = mog.rows * mog.cols
-    scratch = np.empty(5 * n, np.uint8)
+    # the work buffers live with the model (no 66 MB of fresh pages per 4K frame); the frame is copied row block by
+    # row block inside the oracle's workers
+    if getattr(mog, "_work", None) is None:
+        mog._work = (np.empty(frame.size, np.uint8), np.empty(5 * n, np.uint8))
+    work, scratch = mog._work
     thr = np.empty((mog.rows, mog.cols), np.uint8)
     d = Detection()
-    lib.oat_chain_step(mog.h, _p(frame), mog.rows, mog.cols, float(lr), C.byref(p),
-                       _p(scratch), _p(thr), C.byref(d), int(nthreads))
+    lib.oat_chain_step_from(mog.h, _p(frame), _p(work), mog.rows, mog.cols, float(lr), C.byref(p),
+                            _p(scratch), _p(thr), C.byref(d), int(nthreads))
     return d.as_dict(), thr
 
 

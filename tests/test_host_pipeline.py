@@ -379,6 +379,35 @@ def test_batched_tracker_four_cameras_match_their_oracles(host_bins, tmp_path, r
     assert len(areas) >= ncam                     # the cameras really saw different things
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncam,devices", [(4, "0,0"), (3, "0,0"), (2, "0,0,0")])
+def test_batched_tracker_sharded_over_device_contexts(host_bins, tmp_path, ncam, devices):
+    """`oat-track-hip --gpu-index D0,D1,..`: the C++ launcher of SURVEY 8e's partition -- the SOURCE list cut into
+    contiguous blocks, one batched tracker (own context, own thread) per listed device.  On a one-GPU box the same
+    device is listed more than once: two or three contexts on device 0, even and uneven blocks, more devices than
+    cameras.  Every camera must equal ITS oracle, token by token.  (BASELINE configs[3] / [4] are this with eight
+    devices; unmeasured on multi-GPU hardware.)"""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 16
+    streams = [SyntheticStream(rows, cols, 40 + s, n_discs=1, radius=8 + 3 * s) for s in range(ncam)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
+    got = _run_batched(host_bins, tmp_path, frames, ring=2, extra=("--gpu-index", devices))
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    for s in range(ncam):
+        assert len(got[s]) == n, (s, len(got[s]))
+        orc = O.Mog2(rows, cols, 3)
+        hits = 0
+        for t, (f, g) in enumerate(zip(frames[s], got[s])):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], (s, t, g)
+            if want["valid"]:
+                hits += 1
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
+        assert hits >= n - 3, (s, hits)
+
+
 def _write_pnm(path, img):
     img = np.ascontiguousarray(img, np.uint8)
     if img.ndim == 2:
