@@ -586,7 +586,11 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // hold no live slot at k or behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already
     // ends the walk two dead slots in, and the guards cost more vector instructions than they save; (ii) loading the
     // record of a live slot 1 also on lanes that matched, so that frame 2 seldom needs a round trip of its own: 122.1
-    // against 121.8 us.)
+    // against 121.8 us; (iii) a wave taking 2 or 4 mask words one after the other and carrying the NEXT word's counter
+    // bytes along, so that everything the counter byte decides -- weights and records of live slots -- is loaded with
+    // phase 1 instead of a round trip later: 118 us -> 172 us (2 words, 32 B of scratch), 213 us (4 words, 48 B),
+    // 139 us (4 words at 7 waves/SIMD, 8 B) -- and the restructured source cost the streaming-load instantiation 20 B of
+    // scratch and 15 % (298 -> 343 us): reverted.)
     int mask = 0, nnew = nold;
     if (work) {
         mog2_mode<CH, 1, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
