@@ -35,7 +35,8 @@ namespace oatgpu {
 // two-frame launch, 16 x 1080p 558 -> 477 us, one 1080p stream 39.0 -> 34.6 us -- with MORE vector instructions per
 // wave (515 against 504): the kernel is bound by its chain of dependent memory round trips, not by its instruction
 // count.  The streaming-load instantiations (dense models) keep scalar registers: with every lane loading every
-// record, four loads in flight per wave at once ran the dense 4K launch at 324-329 us against 293-295 us.  GREY
+// record, the tuple form ran the dense 4K launch at 324-329 us against 293-295 us at 8 waves/SIMD and 296-298 us held
+// at 7 waves by unused LDS -- no gain over the scalar form's 291-296 us (profiles/r03b_k1_ab.txt).  GREY
 // keeps scalars too (8-byte records; its tuple form is not written).
 template <int CH, bool TUP> struct PxModel;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
