@@ -561,6 +561,32 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 
     const bool work = valid;
 
+    // Two frames a launch: which lanes will be full in FRAME 2 although they are not in frame 1 -- known already (r03).
+    // A lane that is not full has just matched its mode 0: that mode took its update above, it cannot move (mode 0 has
+    // nowhere to bubble to), and nothing else of the lane's variances and means changes in frame 1.  Frame 2's mode-0
+    // test reads exactly those registers (and `total` = 0), so its outcome is what this computes -- bit for bit, the
+    // same expressions mog2_mode<0> evaluates a frame later.  Their records are then fetched in THIS phase 2 together
+    // with frame 1's, and frame 2 has no memory round trip of its own: a wave's chain of dependent round trips is
+    // three no longer, but two.
+    // (Not in the streaming-load instantiations: on a dense model every lane is full in frame 1 anyway.)
+    bool want2 = false;
+#ifdef OATGPU_NO_EARLY2              // (make variant DEFS=-DOATGPU_NO_EARLY2: the A/B build)
+    constexpr bool kEarly2 = false;
+#else
+    constexpr bool kEarly2 = NF == 2 && !NTLD;
+#endif
+    if (kEarly2) {
+        const float z0 = (float)(px2 & 255u), z1 = (float)((px2 >> 8) & 255u), z2 = (float)(px2 >> 16);
+        const float var = rv(pm, 0);
+        const float e0 = rm<0>(pm, 0) - z0;
+        const float e1 = CH == 3 ? rm<1>(pm, 0) - z1 : 0.f;
+        const float e2 = CH == 3 ? rm<2>(pm, 0) - z2 : 0.f;
+        const float dist2 = CH == 3 ? e0 * e0 + e1 * e1 + e2 * e2 : e0 * e0;
+        const bool bg2 = 0.f < a.mp.TB && dist2 < a.mp.Tb * var;
+        const bool fit2 = dist2 < a.mp.Tg * var;
+        want2 = valid && !full && !(fit2 && bg2);
+    }
+
     // ---- phase 2: slots 1..n-1 ----
     {
 #pragma unroll
@@ -568,7 +594,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             const bool have = valid && k < nold;
             const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
             if (lw) pm.w[k] = LDW(k);
-            const bool lr = have && full;
+            const bool lr = have && (full || want2);
             if (lr) ld_rec(k);
             AU_DW(lw, false);
             AU_REC(lr, false);
@@ -637,17 +663,19 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         bool wchg2 = false;
         if (valid) mog2_mode<CH, 0, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
         const bool full2 = valid && !(lq.fits && lq.background);
-        // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
-        const bool need2 = full2 && !full;
+        if (!kEarly2) {
+            // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
+            const bool need2 = full2 && !full;
 #pragma unroll
-        for (int k = 1; k < kMaxMix; ++k) {
-            const bool l2 = need2 && k < nold2;
-            if (l2) ld_rec(k);
-            AU_REC(l2, false);
+            for (int k = 1; k < kMaxMix; ++k) {
+                const bool l2 = need2 && k < nold2;
+                if (l2) ld_rec(k);
+                AU_REC(l2, false);
+            }
+#pragma unroll
+            for (int k = 1; k < kMaxMix; ++k)
+                pin_rec(k, false);
         }
-#pragma unroll
-        for (int k = 1; k < kMaxMix; ++k)
-            pin_rec(k, false);
         int mask2 = 0, nnew2 = nold2;
         if (work) {
             mog2_mode<CH, 1, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
