@@ -1,16 +1,19 @@
 #!/bin/bash
-# Round-2 evidence, collected on the GPU box from the repo root:   bash profiles/collect_r02.sh [tag]
-#   1. the default bench line (4k1 + in-run dense leg + PMC child passes + extra workloads + cpu_baseline)
-#   2. rocprofv3 --kernel-trace --stats of the dense 4K run (the roofline leg) and of the benched sparse 4K run:
-#      the k_mog_fused averages there must agree with roofline.avg_launch_ms / benched_workload.avg_launch_ms
-#   3. SQ-side counters of k_mog_fused (what the kernel is bound by)
+# Round-3 evidence, collected on the GPU box from the repo root:   bash profiles/collect_r03.sh [tag]
+#   1. the default bench line and the line with the driver's arguments (--steps 20 --warmup 5)
+#   2. rocprofv3 --kernel-trace --stats of the default command (profiles/trace_default.sh: per instantiation of
+#      k_mog_fused, medians to hold against the line's HIP-event averages)
+#   3. rocprofv3 --kernel-trace --stats of the dense and of the benched 4K run (back-half kernels beside K1)
+#   4. SQ-side counters of k_mog_fused on both
 # Output under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.log
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_args.json 2> $O/${TAG}_bench_driver_args.log
+bash profiles/trace_default.sh $TAG > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for leg in dense sparse; do
   args="--workload 4k1 --steps 300 --warmup 100 --quick --no-parity --no-spin-up"

@@ -2,7 +2,7 @@
 # rocprofv3 --kernel-trace --stats of THE DEFAULT COMMAND (python bench.py; only the nested rocprofv3 PMC child passes
 # are left out: --no-pmc), summarised per instantiation of the per-pixel kernel and launch geometry, beside the line
 # the traced run printed:   bash profiles/trace_default.sh [tag]   -> gpurun_out/<tag>_trace_default.md
-TAG=${1:-r02g}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O

@@ -169,6 +169,32 @@ def test_mog2_row_parallel_equals_serial():
         assert (x == y).all()
 
 
+def test_chain_on_the_worker_pool_is_independent_of_the_thread_count_and_leaves_its_input_alone():
+    """oracle/pool.c: persistent row workers, woken per stage.  The whole chain (MOG2 + setTo + HSV + inRange + erode +
+    dilate + contours) must give the same detection, threshold image and model for 1, 3, 8 and 40 workers -- growing and
+    shrinking the job count between calls -- and must not touch the caller's frame (the workers copy their rows)."""
+    from oat_amd.synth import SyntheticStream
+    rows, cols = 90, 140
+    st = SyntheticStream(rows, cols, 3, n_discs=1, radius=9)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(10)]
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=10.0, max_area=1e5)
+    runs = {}
+    for order, nts in enumerate(((1,) * 10, (3, 40, 8, 1, 40, 3, 8, 8, 40, 2))):
+        m = O.Mog2(rows, cols, 3)
+        out = []
+        for f, nt in zip(frames, nts):
+            keep = f.copy()
+            d, thr = O.chain_step(m, f, 0.02, p, nthreads=nt)
+            assert (f == keep).all()
+            out.append((d, thr.copy()))
+        runs[order] = (out, m.state())
+    for (d1, t1), (d2, t2) in zip(runs[0][0], runs[1][0]):
+        assert d1 == d2 and (t1 == t2).all()
+    for x, y in zip(runs[0][1], runs[1][1]):
+        assert (x == y).all()
+    assert sum(d["valid"] for d, _ in runs[0][0]) >= 4
+
+
 def test_blur_known_answers_and_dilation_equivalence():
     """cv::blur semantics (DifferenceDetector.cpp:160-161) and the property the GPU path relies on:
     for k <= 22 the box blur of a {0,255} image is non-zero exactly where the k x k dilation is,

@@ -144,6 +144,9 @@ def check(libs):
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libs = sys.argv[1:] or [os.path.join(here, "oat_amd", "lib", "liboatgpu.so")]
+    if not os.path.exists(OBJDUMP):
+        print(f"isa_hazard_check: {OBJDUMP} not found -- binary NOT checked")
+        sys.exit(0)
     bad, n_stores, n_funcs = check(libs)
     for name, addr, ins, a2, nxt, ws, hit in bad:
         print(f"HAZARD {name}: {addr:#x} `{ins}` then after {ws} wait state(s) {a2:#x} `{nxt}` writes v{hit}")
