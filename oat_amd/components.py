@@ -311,14 +311,20 @@ class HotPath(_Context):
         self._chk(self.lib.oatgpu_track_batch_dev(self.ctx, C.c_void_p(dev_ptr), self.learning_coeff_, self._pos))
         return self._out()
 
-    def track_sequence_dev(self, dev_ptrs):
+    def track_sequence_dev(self, dev_ptrs, timed=False):
         """A recorded sequence in one call (oatgpu_track_sequence_dev): dev_ptrs[t] = device address of
-        frame set t; returns one list of Position2D per frame."""
+        frame set t; returns one list of Position2D per frame -- and, with timed=True
+        (oatgpu_track_sequence_dev_timed), the seconds after the call's entry at which each frame's result was collected."""
         n = len(dev_ptrs)
         arr = (C.c_void_p * n)(*dev_ptrs)
         out = (ffi.Position * (n * self.n_streams))()
-        self._chk(self.lib.oatgpu_track_sequence_dev(self.ctx, arr, n, self.learning_coeff_, out))
-        return [[Position2D.from_c(out[t * self.n_streams + s]) for s in range(self.n_streams)] for t in range(n)]
+        if timed:
+            done = (C.c_double * max(n, 1))()
+            self._chk(self.lib.oatgpu_track_sequence_dev_timed(self.ctx, arr, n, self.learning_coeff_, out, done))
+        else:
+            self._chk(self.lib.oatgpu_track_sequence_dev(self.ctx, arr, n, self.learning_coeff_, out))
+        res = [[Position2D.from_c(out[t * self.n_streams + s]) for s in range(self.n_streams)] for t in range(n)]
+        return (res, [done[t] for t in range(n)]) if timed else res
 
     def enqueue(self, frames):
         """Pipelined host-frame form (oatgpu_track_enqueue): frames must stay untouched until the

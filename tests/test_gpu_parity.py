@@ -947,6 +947,11 @@ def test_track_sequence_equals_frame_by_frame(A):
     want = [b.track(list(f)) for f in frames]
     assert got == want and sum(p.position_valid for r in got for p in r) >= 30
     assert a.track_sequence_dev([]) == []
+    # ... and the timed form (bench.py's block timing): same results, collection times ascending from the call's entry
+    c = A.HotPath(rows, cols, ring_depth=5, **kw)
+    got_t, done = c.track_sequence_dev([t.data_ptr() for t in bufs], timed=True)
+    assert got_t == want and len(done) == len(bufs)
+    assert done[0] > 0 and all(y >= x for x, y in zip(done, done[1:])) and done[-1] < 5.0
     a.enqueue_dev(bufs[0].data_ptr())
     with pytest.raises(A.OatGpuError):
         a.track_sequence_dev([bufs[1].data_ptr()])          # results outstanding
