@@ -448,7 +448,14 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     auto ld_rec = [&](int k) {                                      // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
         if constexpr (TUP) {
+#ifdef OATGPU_GLOBAL_REC_LOADS       // (A/B: the `uniform pointer + lane offset` form, two 64-bit address instructions per load)
             pm.r[k] = *(const f32x4 *)rp;
+#else
+            // through the buffer resource: address = lane offset (a register the stores use anyway) + a scalar -- no vector
+            // instruction per load (r02 measured this form slower in the scalar-register kernel, which was not yet bound by
+            // its instruction count)
+            pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), 0));
+#endif
         } else if constexpr (CH == 3) {
             if (NTLD && k >= 1) {
                 const f32x4 q = __builtin_nontemporal_load((const f32x4 *)rp);
@@ -493,6 +500,16 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         else asm volatile("" : "+v"(pm.v[k]), "+v"(pm.m[k][0]));
     };
     uint8_t *nmbase = a.nmodes + (size_t)s * g.Palloc;
+#ifdef OATGPU_CUT                    // measurement only (tools: make variant DEFS=-DOATGPU_CUT=n): end the kernel at cut n with everything
+                                     // computed so far kept alive through one store -- SQ_INSTS_VALU of the variants gives the
+                                     // dynamic instruction count of every region (results are invalid)
+#define CUT(n) do { if (OATGPU_CUT == (n)) { float acc_ = 0.f; _Pragma("unroll") for (int k_ = 0; k_ < kMaxMix; ++k_) \
+        acc_ += pm.w[k_] + rv(pm, k_) + rm<0>(pm, k_) + rm<1>(pm, k_) + rm<2>(pm, k_); \
+        ((float *)a.nmodes)[0] = acc_ + (float)(cut_extra_); return; } } while (0)
+    int cut_extra_ = 0;
+#else
+#define CUT(n) do { } while (0)
+#endif
     const unsigned coff = p;
     // a word's 64 pixels lie in one row (Wp is a multiple of 64): row = widx / words, by multiply-high
     const unsigned y = g.words == 1 ? widx : (unsigned)(((u64)widx * g.words_magic) >> 32);
@@ -506,8 +523,9 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // ---- phase 1: counter byte, mode 0, the pixel -- for every lane, nothing depends on anything ----
     // Everything starts at 0: a slot that is not loaded is dead, and its weight 0 takes part in the arithmetic.
     // (Leaving the {variance, mean} registers of slots >= 1 undefined instead -- read only by lanes that loaded or wrote
-    // them -- saves 16 v_mov a launch but cost the two-frame BGR instantiation 16 bytes of scratch at 64 registers and
-    // 14 % of its speed: measured and not adopted, profiles/r03b_k1_ab.txt.)
+    // them -- saves 16 v_mov a launch: with scalar registers it cost 16 bytes of scratch and 14 %; with register tuples
+    // it is free of scratch, parity-green, and changes the launch time by nothing (110.6 against 110.6 us): not adopted,
+    // profiles/r03b_k1_ab.txt.)
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
         pm.w[k] = 0.f;
@@ -558,6 +576,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
     // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
     const bool full = valid && !(lp.fits && lp.background);
+#ifdef OATGPU_CUT
+    cut_extra_ = (int)lp.fits + (int)lp.background + dvm;
+#endif
+    CUT(1);                          // phase 1 + mode 0 of frame 1
 
     const bool work = valid;
 
@@ -611,21 +633,31 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 
     // (r03, measured and rejected, profiles/r03b_k1_ab.txt: (i) skipping iteration k >= 1 on lanes that have fitted and
     // hold no live slot at k or behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already
-    // ends the walk two dead slots in, and the guards cost more vector instructions than they save; (ii) loading the
+    // ends the walk two dead slots in, and the guards cost more vector instructions than they save -- also as ONE
+    // wave-uniform branch round iterations 2..4 (+8 instructions a wave, no time gained); (ii) loading the
     // record of a live slot 1 also on lanes that matched, so that frame 2 seldom needs a round trip of its own: 122.1
     // against 121.8 us; (iii) a wave taking 2 or 4 mask words one after the other and carrying the NEXT word's counter
     // bytes along, so that everything the counter byte decides -- weights and records of live slots -- is loaded with
     // phase 1 instead of a round trip later: 118 us -> 172 us (2 words, 32 B of scratch), 213 us (4 words, 48 B),
     // 139 us (4 words at 7 waves/SIMD, 8 B) -- and the restructured source cost the streaming-load instantiation 20 B of
     // scratch and 15 % (298 -> 343 us): reverted.)
+    CUT(2);                          // + phase 2 loads
     int mask = 0, nnew = nold;
     if (work) {
         mog2_mode<CH, 1, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
         mog2_mode<CH, 2, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
         mog2_mode<CH, 3, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
         mog2_mode<CH, 4, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+#ifdef OATGPU_CUT
+        cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
+        CUT(3);                      // + modes 1..4 of frame 1
+#endif
         mask = mog2_finish<CH, TUP>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg);
     }
+#ifdef OATGPU_CUT
+    cut_extra_ = mask + nnew + dvm + (int)wchg;
+#endif
+    CUT(4);                          // + finish of frame 1
 
     // frame.setTo(0, mask == 0): shadows (127) stay foreground
     if (mask == 0) { b = 0; gg = 0; r = 0; }
@@ -701,6 +733,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         nnew = nnew2;
     }
 
+#ifdef OATGPU_CUT
+    cut_extra_ = nnew + dvm + (int)wchg + (int)thr + nlive + (int)full_any;
+#endif
+    CUT(5);                          // + HSV / inRange of frame 1 and all of frame 2
     // ---- store back only what changed (values not stored are bit-identical in HBM) ----
     // Weights of slot k >= 1 can only have changed on a full lane (anything goes there) or where the
     // slot was live (decay / renormalisation); a dead slot on a matched lane was 0 and still is.
@@ -724,6 +760,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
     au.run(thr_out && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
+#undef CUT
 #undef LDW
 #undef STW
 #undef SW
