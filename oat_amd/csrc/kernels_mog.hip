@@ -430,9 +430,23 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 //     (the second mode of a flickering pixel and the weights of live slots ARE re-read next frame).  The host picks
 //     NTLD from the model's density, which a sampling kernel measures every 64 frames (k_density_probe).
 //   Mode 0 keeps the default policy either way.
-#define LDW(k) __builtin_bit_cast(float, (NTLD && (k) >= 1) ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
-#define STW(k, v) do { if ((k) >= 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 2); \
-                       else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), 0); } while (0)
+// r03 (profiles/r03b_k1_ab.txt section 11, interleaved A/B on one box): on an EVERYDAY model mode 0 -- the bulk of the
+// traffic, touched once per launch -- is loaded and stored with the streaming policy too, which leaves the caches to what the
+// second round trip of a wave asks for (weights and records of live slots): 4K 114.2 -> 107.5 us per two-frame launch,
+// 16 x 1080p 464.6 -> 425.3 us.  On a dense model (NTLD) it is the other way round, as r02 found: mode 0 default, slots 1..4
+// streaming (mode 0 streaming there: 302.9 -> 305.6 us).  Loads only: worse (114.4 us); stores of slots 1..4 with the default
+// policy: worse.
+#ifdef OATGPU_M0_DEFAULT_POLICY      // (make variant DEFS=-DOATGPU_M0_DEFAULT_POLICY: the A/B build)
+#define OATGPU_M0_LD 0
+#define OATGPU_M0_ST 0
+#else
+#define OATGPU_M0_LD ((CH == 3 && !NTLD) ? 2 : 0)
+#define OATGPU_M0_ST ((CH == 3 && !NTLD) ? 2 : 0)
+#endif
+#define OATGPU_K_ST 2
+#define LDW(k) __builtin_bit_cast(float, (k) == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), OATGPU_M0_LD) : NTLD ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
+#define STW(k, v) do { if ((k) >= 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), OATGPU_K_ST); \
+                       else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), OATGPU_M0_ST); } while (0)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     // Records are LOADED through `uniform pointer + 32-bit lane offset` global loads.  Measured alternatives (r02,
@@ -454,7 +468,8 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             // through the buffer resource: address = lane offset (a register the stores use anyway) + a scalar -- no vector
             // instruction per load (r02 measured this form slower in the scalar-register kernel, which was not yet bound by
             // its instruction count)
-            pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), 0));
+            if (k == 0) pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), OATGPU_M0_LD));
+            else pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), 0));
 #endif
         } else if constexpr (CH == 3) {
             if (NTLD && k >= 1) {
@@ -478,8 +493,8 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
                 q.x = __builtin_bit_cast(unsigned, pm.v[k]); q.y = __builtin_bit_cast(unsigned, pm.m[k][0]);
                 q.z = __builtin_bit_cast(unsigned, pm.m[k][1]); q.w = __builtin_bit_cast(unsigned, pm.m[k][2]);
             }
-            if (k >= 1) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 2);
-            else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), 0);
+            if (k >= 1) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), OATGPU_K_ST);
+            else __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voff_r, SR(k), OATGPU_M0_ST);
             // gfx950 wide-store data hazard (tools/store_hazard_repro.hip): a store of more than 64
             // bits reads its data VGPRs for a few cycles after issue, and hipcc (ROCm 7.2) -- which takes a buffer
             // store with an SGPR soffset to be exempt -- may overwrite one of them in the very next instruction.
