@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 #define OATGPU_M0_ST ((CH == 3 && !NTLD) ? 2 : 0)
 #endif
 #define OATGPU_K_ST 2
+// (the frames' bytes and the counter bytes with the streaming policy: no change either way, profiles/r03b_k1_ab.txt section 12)
 #define LDW(k) __builtin_bit_cast(float, (k) == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), OATGPU_M0_LD) : NTLD ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
 #define STW(k, v) do { if ((k) >= 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), OATGPU_K_ST); \
                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), rsrc, voff_w, SW(k), OATGPU_M0_ST); } while (0)
