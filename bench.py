@@ -995,7 +995,6 @@ def main():
                 # the same leg on an input whose pixels all STAY background (noise +-3 instead of +-5: no lane of any wave
                 # runs detectShadowGMM, ~400 vector instructions a wave in the leg above): the bytes without the extra arithmetic
                 try:
-                    global DENSE_NOISE
                     keep_noise, DENSE_NOISE = DENSE_NOISE, 3
                     dq = Leg("4k1", local_rank, rank, dense=True, pool=10)
                     DENSE_NOISE = keep_noise
