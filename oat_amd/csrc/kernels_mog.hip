@@ -566,15 +566,6 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         if (CH == 3) { gg = frame[fj + 1]; r = frame[fj + 2]; }
         au.run(valid, CH, false);
     }
-#ifdef OATGPU_PREFETCH_WORDS          // A/B (r03): warm the caches for a LATER wave's second round trip.  The word OATGPU_PREFETCH_WORDS
-    // ahead (a multiple of 32: same XCD, whose L2 is its own) is taken by a wave that starts a few microseconds from now; its
-    // counter bytes ride with this wave's phase 1, and behind this wave's last load wait one-byte loads touch that word's
-    // slot-1 weight and record sectors on the lanes whose hint says "live" -- into a register nobody reads.
-    int cpf = 0;
-    constexpr bool kPrefetch = TUP && NF == 2 && !AUDIT;
-    const bool pf_in = kPrefetch && !a.fresh && (int)((widx + OATGPU_PREFETCH_WORDS) * kWavePx) < g.P;
-    if (pf_in) cpf = nmbase[coff + OATGPU_PREFETCH_WORDS * kWavePx];
-#endif
     unsigned px2 = 0;                             // NF == 2: the second frame's pixel, packed b | g << 8 | r << 16
     if (NF == 2) {
         const uint8_t *frame2 = a.frames2 + (size_t)s * npx * CH;
@@ -656,21 +647,15 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 #pragma unroll
     for (int k = 1; k < kMaxMix; ++k)
         pin_rec(k, true);
-#ifdef OATGPU_PREFETCH_WORDS
-    unsigned pf_trash = 0;
-    if (pf_in && ((cpf >> (kLiveShift + 1)) & 1))
-        asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen\n\tbuffer_load_ubyte %0, %4, %2, %5 offen"
-                     : "=v"(pf_trash)
-                     : "v"(voff_w + OATGPU_PREFETCH_WORDS * kWavePx * 4u), "s"(rsrc), "s"(SW(1)),
-                       "v"(voff_r + OATGPU_PREFETCH_WORDS * kWavePx * 4u * (1 + CH)), "s"(SR(1)));
-#endif
 
     // (r03, measured and rejected, profiles/r03b_k1_ab.txt: (i) skipping iteration k >= 1 on lanes that have fitted and
     // hold no live slot at k or behind it -- exact under `nmodes = nNewModes;` -- does not pay: the running count already
     // ends the walk two dead slots in, and the guards cost more vector instructions than they save -- also as ONE
     // wave-uniform branch round iterations 2..4 (+8 instructions a wave, no time gained); (ii) loading the
     // record of a live slot 1 also on lanes that matched, so that frame 2 seldom needs a round trip of its own: 122.1
-    // against 121.8 us; (iii) a wave taking 2 or 4 mask words one after the other and carrying the NEXT word's counter
+    // against 121.8 us; (iv) warming the L2 for a later wave of the same XCD (the counter bytes of the word 2 048 / 8 192 /
+    // 16 384 ahead ride with phase 1; behind the last load wait, byte loads touch that word's live slot-1 weight and record
+    // sectors into a register nobody reads): 105.7 -> 112.5 us whatever the distance; (iii) a wave taking 2 or 4 mask words one after the other and carrying the NEXT word's counter
     // bytes along, so that everything the counter byte decides -- weights and records of live slots -- is loaded with
     // phase 1 instead of a round trip later: 118 us -> 172 us (2 words, 32 B of scratch), 213 us (4 words, 48 B),
     // 139 us (4 words at 7 waves/SIMD, 8 B) -- and the restructured source cost the streaming-load instantiation 20 B of
@@ -793,9 +778,6 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     u64 *const thr_out = NF == 2 ? a.thr_bits2 : a.thr_bits;
     if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
     au.run(thr_out && lane == 0, 8, true);
-#ifdef OATGPU_PREFETCH_WORDS
-    asm volatile("" :: "v"(pf_trash));            // the register stays the prefetch loads' until the wave ends
-#endif
     au.flush(a.audit, lane, valid);
 #undef CUT
 #undef LDW
