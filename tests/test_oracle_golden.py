@@ -110,6 +110,48 @@ def test_mog2_single_pixel_traces(golden_dir):
     assert {"prune_revive", "prune_revive_shrink", "alpha05", "alpha05_shrink"} <= names
 
 
+@pytest.mark.parametrize("restore", [1, 0])
+@pytest.mark.parametrize("rate", [0.3, 0.02, -1.0])
+def test_mog2_random_pixels_against_the_python_restatement(restore, rate):
+    """The per-pixel Python restatement that made the golden traces (tests/golden/make_golden.py, written from the
+    description of MOG2Invoker, float32 step by step) on RANDOM pixel histories -- two-level flicker, slow drift, rare
+    outliers, enough to prune, revive and replace modes -- against the C oracle run on all of them as one image:
+    mask, mode count, weights, variances, means of every pixel and frame, bit for bit, for both readings of the count."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    rng = np.random.default_rng(41 + restore)
+    npx, nfr = 24, 45
+    base = rng.integers(30, 220, (npx, 3))
+    alt = rng.integers(0, 256, (npx, 3))
+    frames = np.empty((nfr, npx, 3), np.uint8)
+    for t in range(nfr):
+        f = base + rng.integers(-6, 7, (npx, 3)) + (t // 9)
+        flip = rng.random(npx) < 0.25
+        f[flip] = alt[flip] + rng.integers(-3, 4, (int(flip.sum()), 3))
+        wild = rng.random(npx) < 0.05
+        f[wild] = rng.integers(0, 256, (int(wild.sum()), 3))
+        frames[t] = np.clip(f, 0, 255)
+    m = O.Mog2(1, npx, 3, params=dict(restore_nmodes=restore))
+    got = []
+    for t in range(nfr):
+        mask = m.apply(frames[t].reshape(1, npx, 3), rate)
+        nm, w, v, mu = m.state()
+        got.append((mask[0].copy(), nm.copy(), w.copy(), v.copy(), mu.copy()))
+    for p in range(npx):
+        tr = G.mog2_pixel_trace([tuple(int(c) for c in frames[t, p]) for t in range(nfr)], [rate] * nfr, restore=bool(restore))
+        for t, want in enumerate(tr):
+            mask, nm, w, v, mu = got[t]
+            k = want["nmodes"]
+            assert int(mask[p]) == want["mask"] and int(nm[p]) == k, (p, t)
+            assert w[p, :k].tolist() == [np.float32(x) for x in want["weight"]], (p, t)
+            assert v[p, :k].tolist() == [np.float32(x) for x in want["variance"]], (p, t)
+            assert mu[p, :k].tolist() == [[np.float32(c) for c in r] for r in want["mean"]], (p, t)
+    counts = np.stack([g[1] for g in got])
+    assert counts.max() == 5 and (counts[-1] >= 2).sum() >= npx // 2          # the histories really exercised the mixture
+
+
 def test_mog2_mode_count_readings_differ_only_after_a_prune():
     """restore_nmodes = 1 (MOG2Invoker's `nmodes = nNewModes;`): modesUsed never decreases and a pruned
     slot keeps weight 0; restore_nmodes = 0: the count shrinks.  Before the first prune the two readings
