@@ -143,6 +143,12 @@ const char *oatgpu_last_error(const oatgpu_ctx *ctx);
  * stage-by-stage calls may live anywhere; when they live in page-locked memory (a shared-memory
  * segment registered with oatgpu_host_register, or a buffer from oatgpu_host_alloc) the copies
  * are direct DMA instead of bounce-buffered. */
+/* Devices and where they hang: oatgpu_device_count() HIP devices are visible; oatgpu_device_numa_node(i) is the NUMA node
+ * of device i's PCIe slot (from its bus id through sysfs), -1 if unknown.  A multi-device component keeps the thread that
+ * drives device i on that node's CPUs (host/oat_track_hip.cpp --gpu-index D0,D1,..): its launches, its shared-memory reads
+ * and the staging copies then stay on the socket the GPU is attached to.  No reference counterpart. */
+int oatgpu_device_count(void);
+int oatgpu_device_numa_node(int32_t device);
 int oatgpu_host_register(void *ptr, size_t bytes);
 int oatgpu_host_unregister(void *ptr);
 void *oatgpu_host_alloc(size_t bytes);

@@ -499,6 +499,27 @@ extern "C" const char *oatgpu_last_error(const oatgpu_ctx *c)
     return c ? c->err.c_str() : g_last_error.c_str();
 }
 
+extern "C" int oatgpu_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+extern "C" int oatgpu_device_numa_node(int32_t device)
+{
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+    for (char *p = bus; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells it in lower case
+    char path[96];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 extern "C" int oatgpu_host_register(void *ptr, size_t bytes)
 {
     if (!ptr || !bytes) return fail(nullptr, OATGPU_E_INVALID, "null argument");

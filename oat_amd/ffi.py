@@ -67,6 +67,8 @@ SIGNATURES = {
     "oatgpu_create": (_ctx, [C.POINTER(Config)]),
     "oatgpu_destroy": (None, [_ctx]),
     "oatgpu_last_error": (C.c_char_p, [_ctx]),
+    "oatgpu_device_count": (C.c_int, []),
+    "oatgpu_device_numa_node": (C.c_int, [C.c_int32]),
     "oatgpu_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "oatgpu_host_unregister": (C.c_int, [C.c_void_p]),
     "oatgpu_host_alloc": (C.c_void_p, [C.c_size_t]),

@@ -32,6 +32,8 @@
 // and the intensity window of SimpleThreshold.cpp:171-174 in the same fused launches.
 #include "component.hpp"
 #include <deque>
+#include <fstream>
+#include <sched.h>
 #include <thread>
 #include <unistd.h>
 
@@ -50,6 +52,31 @@ static std::vector<std::string> split_list(const std::string &s)
         a = b + 1;
     }
     return out;
+}
+
+// Keep the calling thread on the CPUs of the NUMA node device `dev` hangs off (oatgpu_device_numa_node): its launch calls,
+// its reads of the shared-memory frames and the staging copies stay on that socket.  Best effort; false if nothing was done.
+static bool pin_thread_to_device_node(int dev)
+{
+    const int node = oatgpu_device_numa_node(dev);
+    if (node < 0) return false;
+    std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string list;
+    if (!f || !std::getline(f, list)) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    size_t a = 0;
+    int n = 0;
+    while (a < list.size()) {
+        size_t b = list.find(',', a);
+        if (b == std::string::npos) b = list.size();
+        const std::string part = list.substr(a, b - a);
+        const size_t dash = part.find('-');
+        const int lo = atoi(part.c_str()), hi = dash == std::string::npos ? lo : atoi(part.c_str() + dash + 1);
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); ++n; }
+        a = b + 1;
+    }
+    return n > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 class BatchedTracker : public Component {
@@ -262,7 +289,11 @@ int main(int argc, char **argv)
         // through `quit` (the waits are 10 ms slices), END of a shard's SOURCEs ends that shard only
         std::vector<int> rc(shards.size(), 0);
         std::vector<std::thread> th;
-        for (size_t k = 0; k < shards.size(); ++k) th.emplace_back([&, k] { rc[k] = shards[k]->run(); });
+        for (size_t k = 0; k < shards.size(); ++k)
+            th.emplace_back([&, k] {
+                pin_thread_to_device_node(shards[k]->cfg_.device);      // the shard's thread next to its GPU
+                rc[k] = shards[k]->run();
+            });
         for (auto &t : th) t.join();
         for (int r : rc) if (r) return r;
         return 0;

@@ -1498,3 +1498,16 @@ def test_declined_frame_survives_single_stage_calls_and_ready(A):
         r2 = hp.collect()[0]
         _same_detection(r1, O.chain_step(orc, busy, 0.01, p)[0], ("busy", use_ready))
         _same_detection(r2, O.chain_step(orc, calm, 0.01, p)[0], ("calm", use_ready))
+
+
+def test_device_count_and_numa_node(A):
+    """oatgpu_device_count / oatgpu_device_numa_node: what the multi-device tracker pins its shard threads by."""
+    from oat_amd import ffi
+    lib = ffi.load()
+    n = lib.oatgpu_device_count()
+    assert n >= 1
+    node = lib.oatgpu_device_numa_node(0)
+    assert node >= -1
+    if node >= 0:
+        assert os.path.exists(f"/sys/devices/system/node/node{node}/cpulist")
+    assert lib.oatgpu_device_numa_node(n + 5) == -1
