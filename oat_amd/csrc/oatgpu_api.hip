@@ -508,7 +508,8 @@ extern "C" int oatgpu_device_count(void)
 extern "C" int oatgpu_device_numa_node(int32_t device)
 {
     char bus[32] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+    if (device < 0 || device >= oatgpu_device_count()) return -1;             // (never hand HIP a bad ordinal: its error is sticky)
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
     for (char *p = bus; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells it in lower case
     char path[96];
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
