@@ -21,8 +21,10 @@ import bench
 
 def main():
     mode, dense, d = sys.argv[1], "--dense" in sys.argv, sys.argv[-1]
+    if "--quiet" in sys.argv:                      # the dense leg whose pixels all stay background (bench.py roofline.all_background)
+        bench.DENSE_NOISE = 3
     os.makedirs(d, exist_ok=True)
-    tag = "dense" if dense else "sparse"
+    tag = ("quiet" if "--quiet" in sys.argv else "dense") if dense else "sparse"
     if mode == "save":
         leg = bench.Leg("4k1", 0, 0, dense=dense, pool=10 if dense else 48)
         leg.init()
