@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     unsigned short *wpre = b.wpre + ((size_t)s * g.H + y) * g.words;
     unsigned runs_before = 0;   // run starts of this row in earlier chunks
     bool row_fg = false;
+    u64 keepT = 0ull, keepF = 0ull;   // rows of <= 64 words (<= 4096 px): the lane's T and F stay in registers for the loop below
 
     for (int c0 = 0; c0 < g.words; c0 += 64) {
         const int w = c0 + lane;
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             carry[w] = cin;
             wpre[w] = (unsigned short)min(runs_before + incl - cntT, 65535u);
         }
+        keepT = T; keepF = F;
         runs_before += __shfl(incl, 63);
         row_fg = row_fg || __ballot(F != 0ull) != 0ull;
         // carry state into the next chunk (all lanes agree)
@@ -280,8 +282,10 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     for (int c0 = 0; c0 < g.words; c0 += 64) {
         const int w = c0 + lane;
         if (w >= g.words) continue;
-        u64 tt = trans[w];                       // written by this very lane above
-        const u64 F = fin[w];
+        // (written by this very lane above; re-read only when the row has more than one chunk -- the stores are write-
+        // through, the loads were a global round trip of their own)
+        u64 tt = g.words <= 64 ? keepT : trans[w];
+        const u64 F = g.words <= 64 ? keepF : fin[w];
         while (tt) {
             const int i = lsb64(tt);
             tt &= tt - 1;
@@ -612,12 +616,42 @@ constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768;      // 58 KB o
 #ifndef OATGPU_LDS_BLOCK
 #define OATGPU_LDS_BLOCK 1024
 #endif
-// Threads of the one workgroup.  r03 (profiles/r03c_backhalf_under_load.txt): beside the per-pixel kernel this kernel takes
-// 93-96 us at 4K against 21-23 us alone -- not because it waits for a compute unit with 16 free wave slots (rocprof's
-// duration is execution time; 512 / 256 threads, which fit a partly occupied unit, ran 106 / 111 us and cost the one-
-// 1080p-stream workload 16-21 % of its frame rate) and not for want of issue slots (s_setprio 3: no change): its ~15
-// dependent global round trips queue behind the per-pixel kernel's saturated memory system.
+// Threads of the one workgroup.  Beside the per-pixel kernel a launch of this kernel lasts 81-96 us at 4K in a kernel
+// trace, against 21-27 us alone.  What the difference is (r03, tools/lds_phase_probe.py with a -DOATGPU_LDS_TIMING build:
+// the kernel stamps the 100 MHz wall clock between its phases, profiles/r03j_backhalf_slot_wait.txt): the workgroup
+// itself RUNS 26.3 us beside the per-pixel kernel and 25.5 us alone, phase for phase the same -- the other 55 us of
+// the trace's duration pass before its first instruction: 16 waves with 61 KB of LDS need four free wave slots and
+// 288 registers on every SIMD of ONE compute unit, the per-pixel kernel holds 8 waves / all 512 registers per SIMD
+// everywhere and refills every slot a retiring 4-wave workgroup frees, and stream priority does not make the
+// dispatcher hold slots back: the workgroup gets in when the running per-pixel launch drains (half a launch = 53 us
+// on average).  (Earlier in r03 the duration was read as execution time and blamed on memory latency; the in-kernel
+// clock refutes that, and so did removing this kernel's loads.)  Smaller workgroups do get in earlier but run longer:
+// 512 / 256 threads 106 / 111 us and 16-21 % off the one-1080p-stream frame rate; s_setprio 3: no change.  Keeping the
+// per-pixel kernel's stream off 4 / 8 / 16 compute units with a CU mask (hipExtStreamCreateWithCUMask) brings this
+// kernel to 72 / 72 / 38 us and costs the per-pixel kernel 10 % whatever the number (107 -> 118 us per two-frame 4K
+// launch, 17.5 k -> 15.9 k fps): not adopted.  A camera-bound pipeline never sees the wait: no later frame's
+// per-pixel kernel is running when a frame's back half starts.
 constexpr int kLdsBlock = OATGPU_LDS_BLOCK;
+#ifndef OATGPU_LDS_TRIP
+#define OATGPU_LDS_TRIP 8
+#endif
+constexpr int kLdsTrip = OATGPU_LDS_TRIP;      // words of the run-start image a thread has in flight per trip of phase B
+
+#ifdef OATGPU_LDS_TIMING           // measurement builds only (make variant DEFS=-DOATGPU_LDS_TIMING, tools/lds_phase_probe.py)
+constexpr unsigned kLdsTkRing = 4096u;
+__device__ long long g_lds_tk[kLdsTkRing * 10u];
+__device__ unsigned g_lds_tk_n;
+extern "C" __attribute__((visibility("default"))) int oatgpu_debug_lds_timing(long long *out, int max_rows)
+{
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_lds_tk_n), sizeof n) != hipSuccess) return -1;
+    const unsigned rows = n < kLdsTkRing ? n : kLdsTkRing;
+    const unsigned take = rows < (unsigned)max_rows ? rows : (unsigned)max_rows;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_tk), (size_t)take * 10u * sizeof(long long)) != hipSuccess) return -1;
+    return (int)take;
+}
+#endif
 
 __device__ __forceinline__ int lds_find(int *par, int i)
 {
@@ -678,7 +712,17 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     const int per = (g.H + kLdsBlock - 1) / kLdsBlock;
     const int y0 = t * per, y1 = min(y0 + per, g.H);
     unsigned d = 0, rn = 0;
-    for (int y = y0; y < y1; ++y) { const int ri = rowinfo[y]; if (ri) { d++; rn += (unsigned)ri; } }
+    // (r03: the row counts stay in registers for the second pass below when a thread owns <= 4 rows -- frames up to 4096
+    // rows: every dependent global round trip of this kernel costs 4-5 us beside the per-pixel kernel, section header)
+    int ric[4] = {0, 0, 0, 0};
+    if (per <= 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int y = y0 + q; if (y < y1) ric[q] = rowinfo[y]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (ric[q]) { d++; rn += (unsigned)ric[q]; }
+    } else {
+        for (int y = y0; y < y1; ++y) { const int ri = rowinfo[y]; if (ri) { d++; rn += (unsigned)ri; } }
+    }
     unsigned di = d, ri_ = rn;                          // inclusive scans over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -710,23 +754,31 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         }
         return;
     }
-    for (int y = y0; y < y1; ++y) {
-        const int ri = rowinfo[y];
-        if (ri) { rows[dbase] = (unsigned short)y; rptr[dbase] = 1u + rbase; dbase++; rbase += (unsigned)ri; }
+    if (per <= 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ri = ric[q];
+            if (ri) { rows[dbase] = (unsigned short)(y0 + q); rptr[dbase] = 1u + rbase; dbase++; rbase += (unsigned)ri; }
+        }
+    } else {
+        for (int y = y0; y < y1; ++y) {
+            const int ri = rowinfo[y];
+            if (ri) { rows[dbase] = (unsigned short)y; rptr[dbase] = 1u + rbase; dbase++; rbase += (unsigned)ri; }
+        }
     }
     if (t == 0) { rptr[D] = 1u + R; par[0] = 0; }
     __syncthreads();
 
     TK();
-    // ---- B: the run list ----  (four words per thread and trip: the loads of a trip are in flight together)
+    // ---- B: the run list ----  (kLdsTrip words per thread and trip: the loads of a trip are in flight together)
     {
         const unsigned total = D * (unsigned)g.words;
-        for (unsigned i0 = t; i0 < total; i0 += 4u * kLdsBlock) {
-            u64 T[4];
-            unsigned rr[4], pre[4];
-            size_t gi[4];
+        for (unsigned i0 = t; i0 < total; i0 += (unsigned)kLdsTrip * kLdsBlock) {
+            u64 T[kLdsTrip];
+            unsigned rr[kLdsTrip], pre[kLdsTrip];
+            size_t gi[kLdsTrip];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kLdsTrip; ++u) {
                 const unsigned i = i0 + (unsigned)u * kLdsBlock, ic = min(i, total - 1u);   // (no branch round the load)
                 const unsigned r = ic / (unsigned)g.words, w = ic - r * (unsigned)g.words;
                 rr[u] = r;
@@ -736,7 +788,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
                 if (i >= total) T[u] = 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kLdsTrip; ++u) {
                 u64 Tu = T[u];
                 if (!Tu) continue;
                 const unsigned r = rr[u], w = (unsigned)(gi[u] - (size_t)rows[r] * g.words);
@@ -861,7 +913,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
             const int lo = max(sx - w * 64, 0), hi = min(ex - w * 64, 63);
             const u64 runbits = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull) & qbits;
             // the threads of a run need the same nine words: thread 0 of them fetches the run's row, thread 1
-            // the row above, thread 2 the row below, and they pass them round (a quarter of the requests)
+            // the row above, thread 2 the row below, and they pass them round (a quarter of the requests).
+            // (r03: rebuilding the nine words from the run list in LDS instead -- no global load in this phase -- was
+            // parity-green and no faster: 18.4 against 16.3 us alone at 1080p, 84 against 82 us beside the per-pixel
+            // kernel at 4K, gpurun_out/bh1 -> profiles/r03j_backhalf_slot_wait.txt.  The loads are not what this
+            // kernel waits for: see kLdsBlock.)
             const int role = sub;
             const size_t rbase = role == 0 ? rc : (role == 1 ? ru : rd);
             const bool hp = w > 0, hn = w + 1 < g.words;
@@ -980,7 +1036,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         b.lds_ok[s] = 1u;
 #ifdef OATGPU_LDS_TIMING
         TK();
-        printf("lds D=%u R=%u NR=%u NF=%u  A %lld B %lld C %lld D %lld  E: setup %lld own-loop %lld barrier-wait %lld  F %lld (x10 ns)\n", D, R, NR, NF, tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4], tk[6]-tk[5], tk[7]-tk[6], tk[8]-tk[7]);
+        // (a ring in device memory, read by oatgpu_debug_lds_timing: a printf here takes 400 us and turns "beside the
+        // per-pixel kernel" into "alone")
+        const unsigned slot = atomicAdd(&g_lds_tk_n, 1u) & (kLdsTkRing - 1u);
+        for (int q = 0; q < 9; ++q) g_lds_tk[slot * 10u + q] = tk[q];
+        g_lds_tk[slot * 10u + 9] = (long long)D << 32 | R;
 #endif
     }
 }

@@ -257,6 +257,17 @@ bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
     std::lock_guard<std::mutex> lk(g_streams_mutex);
     DeviceStreams &d = g_streams[device];
     if (!d.a) {
+        // (measurement builds: OATGPU_A_RESERVE=n keeps stream A -- the per-pixel kernel -- off the last n compute units)
+        int reserve = 0;
+        if (const char *e = measure_env("OATGPU_A_RESERVE")) reserve = atoi(e);
+        if (reserve > 0) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+            const int ncu = prop.multiProcessorCount;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu - reserve; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&d.a, (uint32_t)mask.size(), mask.data()) != hipSuccess) { d.a = nullptr; return false; }
+        } else
         if (hipStreamCreateWithFlags(&d.a, hipStreamNonBlocking) != hipSuccess) { d.a = nullptr; return false; }
         for (int q = 0; q < oatgpu_ctx::kNB - 1; ++q)            // A + 3 B streams = the four queues
             if (!(d.b[q] = create_b_stream())) return false;
