@@ -136,8 +136,10 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 set_rm<0>(s, MODE, rm<0>(s, MODE) - k * d0);
                 if (CH == 3) { set_rm<1>(s, MODE, rm<1>(s, MODE) - k * d1); set_rm<2>(s, MODE, rm<2>(s, MODE) - k * d2); }
                 float varnew = var + k * (dist2 - var);
-                varnew = varnew > P.varMin ? varnew : P.varMin;
-                varnew = varnew < P.varMax ? varnew : P.varMax;
+                // MAX(varnew, varMin) then MIN(.., varMax) of the reference's macros -- as v_max_f32 / v_min_f32: with a
+                // NaN on the left the macro yields the bound, and so does the instruction (the bounds are never NaN)
+                varnew = __builtin_fmaxf(varnew, P.varMin);
+                varnew = __builtin_fminf(varnew, P.varMax);
                 set_rv(s, MODE, varnew);
                 dvm |= (1u << MODE);
                 // The reference bubbles the OLD weight up and then stores the new one
@@ -387,6 +389,32 @@ struct Audit {
 #ifndef OATGPU_F2_WAVES
 #define OATGPU_F2_WAVES 8
 #endif
+// Late arguments (r03).  The kernel's by-value arguments sit in scalar registers from the first instruction on, and at 8
+// waves per SIMD a wave has 80 of them (800 per SIMD / 8, less the trap handler's 16): the two-frame BGR instantiation
+// spilled 31 scalars to lanes of a vector register -- 61 v_writelane / v_readlane on a kernel bound by its vector
+// instruction count.  What is only needed late (the second frame's rates and parameters, the inRange window, the
+// threshold-word pointers) is therefore read where it is needed, by scalar loads from the kernarg segment through a
+// pointer the compiler cannot see through (KRELOAD): SMEM instead of VALU work, and short live ranges.
+typedef const MogLaunch __attribute__((address_space(4))) *KArgs;
+typedef const char __attribute__((address_space(4))) *KBytes;
+constexpr unsigned kMogLaunchArgOffset = (unsigned)((sizeof(Geom) + alignof(MogLaunch) - 1) / alignof(MogLaunch) * alignof(MogLaunch));
+#define KRELOAD(ka) asm volatile("" : "+s"(ka))
+__device__ __forceinline__ MogParams karg_mp(KArgs ka)
+{
+    MogParams P;
+    P.Tb = ka->mp.Tb; P.TB = ka->mp.TB; P.Tg = ka->mp.Tg; P.varInit = ka->mp.varInit; P.varMin = ka->mp.varMin;
+    P.varMax = ka->mp.varMax; P.tau = ka->mp.tau; P.nmix = ka->mp.nmix; P.detectShadows = ka->mp.detectShadows;
+    P.shadowVal = ka->mp.shadowVal; P.restoreCount = ka->mp.restoreCount;
+    return P;
+}
+__device__ __forceinline__ RangeParams karg_rp(KArgs ka)
+{
+    RangeParams r;
+    r.lo[0] = ka->rp.lo[0]; r.lo[1] = ka->rp.lo[1]; r.lo[2] = ka->rp.lo[2];
+    r.hi[0] = ka->rp.hi[0]; r.hi[1] = ka->rp.hi[1]; r.hi[2] = ka->rp.hi[2];
+    return r;
+}
+
 template <int CH, bool AUDIT, bool NTLD, int NF>
 __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
@@ -396,6 +424,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     static_assert(NF == 1 || !AUDIT || CH == 3, "the audited two-frame instantiation exists for BGR only");
 
     Audit<AUDIT> au;
+    // (late arguments: the product two-frame BGR instantiation only -- the others are not bound by their instruction count
+    // or were left as compiled)
+    constexpr bool kLate = !NTLD && !AUDIT && CH == 3;
+    KArgs ka = (KArgs)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + kMogLaunchArgOffset);
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
     // 79 % VALU-busy at 370 VALU instructions per wave before, profiles/r02_k1_sq_counters_before.md): every plane
     // access is `buffer resource + one shared lane offset + scalar plane offset`, the row of a wave comes from a
@@ -533,6 +565,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     const unsigned x = (widx - y * (unsigned)g.words) * 64u + lpos;
     const bool valid = active && (x < (unsigned)g.W);
     const unsigned fi = (y * (unsigned)g.W + x) * CH;                        // frames stay below 4 GiB per stream
+    const bool zero_in = kLate && in_range3(0, 0, 0, a.rp);      // a zeroed pixel is HSV (0,0,0): one uniform window test
 #define AU_DW(m, wr) au.dword((m), (wr))
 #define AU_REC(m, wr) au.template rec<4 * (1 + CH)>((m), (wr))
 #define AU_B(m, wr) au.byte((m), (wr))
@@ -551,7 +584,13 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     int cnt = 0;
     int b = 0, gg = 0, r = 0;
     // (no `active` guard: the planes are allocated for Palloc pixels, a multiple of the block's 256)
-    if (!a.fresh) {
+    // (two-frame launches are never fresh and never write the masked frame or the mask bytes -- MogLaunch's contract:
+    // their instantiations do not carry those arguments in scalar registers)
+    // (kSingle also covers the streaming-load two-frame instantiation, left as it was: without these arguments the
+    // allocator put it 12 bytes into scratch at its 72 registers)
+    constexpr bool kSingle = NF == 1 || NTLD;
+    const bool fresh = kSingle && a.fresh;
+    if (!fresh) {
         cnt = nmbase[coff];
         pm.w[0] = LDW(0);
         ld_rec(0);
@@ -631,7 +670,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 #pragma unroll
         for (int k = 1; k < kMaxMix; ++k) {
             const bool have = valid && k < nold;
-            const bool lw = have && ((cnt >> (kLiveShift + k)) & 1);
+            const bool lw = have && (cnt & (1 << (kLiveShift + k))) != 0;
             if (lw) pm.w[k] = LDW(k);
             const bool lr = have && (full || want2);
             if (lr) ld_rec(k);
@@ -680,8 +719,8 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
 
     // frame.setTo(0, mask == 0): shadows (127) stay foreground
     if (mask == 0) { b = 0; gg = 0; r = 0; }
-    if (work && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
-    if (work && a.out_bgr) {
+    if (kSingle && work && a.out_mask) a.out_mask[(size_t)(s - a.out_base) * npx + (size_t)y * g.W + x] = (uint8_t)mask;
+    if (kSingle && work && a.out_bgr) {
         uint8_t *o = a.out_bgr + (size_t)(s - a.out_base) * npx * CH + fi;
         o[0] = (uint8_t)b;
         if (CH == 3) { o[1] = (uint8_t)gg; o[2] = (uint8_t)r; }
@@ -690,11 +729,23 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // and a wave without any skips the whole conversion.
     bool thr;
     if (CH == 3) {
-        thr = work && in_range3(0, 0, 0, a.rp);
-        if (mask != 0) {
-            int hh, ss, vv;
-            bgr2hsv_inline(b, gg, r, hh, ss, vv);
-            thr = work && in_range3(hh, ss, vv, a.rp);
+        if (kLate) {
+            thr = work && zero_in;
+            if (mask != 0) {
+                KArgs kb = ka;                               // (a copy: `ka` itself must stay uniform across this divergent region)
+                KRELOAD(kb);
+                const RangeParams rp = karg_rp(kb);
+                int hh, ss, vv;
+                bgr2hsv_inline(b, gg, r, hh, ss, vv);
+                thr = work && in_range3(hh, ss, vv, rp);
+            }
+        } else {
+            thr = work && in_range3(0, 0, 0, a.rp);
+            if (mask != 0) {
+                int hh, ss, vv;
+                bgr2hsv_inline(b, gg, r, hh, ss, vv);
+                thr = work && in_range3(hh, ss, vv, a.rp);
+            }
         }
     } else {                                     // GREY chain: framefilt mog -> posidet thresh
         thr = work && b >= a.rp.lo[0] && b <= a.rp.hi[0];
@@ -705,14 +756,18 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     if (NF == 2) {
         // ---- the second frame, on the registers the first one left ----
         const u64 word1 = __ballot(thr);
-        if (a.thr_bits && lane == 0) a.thr_bits[(size_t)s * nwords + widx] = word1;
-        au.run(a.thr_bits && lane == 0, 8, true);
+        if (kLate) KRELOAD(ka);
+        u64 *const thr1 = kLate ? ka->thr_bits : a.thr_bits;
+        if (thr1 && lane == 0) thr1[(size_t)s * nwords + widx] = word1;
+        au.run(thr1 && lane == 0, 8, true);
+        const MogParams mp2 = kLate ? karg_mp(ka) : a.mp;
+        const float aT2 = kLate ? ka->alphaT2 : a.alphaT2, a12 = kLate ? ka->alpha12 : a.alpha12, pr2 = kLate ? ka->prune2 : a.prune2;
         b = (int)(px2 & 255u); gg = (int)((px2 >> 8) & 255u); r = (int)(px2 >> 16);
         const int nold2 = nnew;
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
         PxLoop lq{false, false, nold2, 0.f};
         bool wchg2 = false;
-        if (valid) mog2_mode<CH, 0, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
+        if (valid) mog2_mode<CH, 0, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
         const bool full2 = valid && !(lq.fits && lq.background);
         if (!kEarly2) {
             // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
@@ -729,19 +784,31 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         }
         int mask2 = 0, nnew2 = nold2;
         if (work) {
-            mog2_mode<CH, 1, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 2, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 3, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mog2_mode<CH, 4, TUP>(pm, lq, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, a.prune2, dvm);
-            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, a.mp, a.alphaT2, a.alpha12, dvm, wchg2);
+            mog2_mode<CH, 1, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 2, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 3, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 4, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
         if (CH == 3) {
-            thr = work && in_range3(0, 0, 0, a.rp);
-            if (mask2 != 0) {
-                int hh, ss, vv;
-                bgr2hsv_inline(b, gg, r, hh, ss, vv);
-                thr = work && in_range3(hh, ss, vv, a.rp);
+            if (kLate) {
+                thr = work && zero_in;
+                if (mask2 != 0) {
+                    KArgs kb = ka;
+                    KRELOAD(kb);
+                    const RangeParams rp = karg_rp(kb);
+                    int hh, ss, vv;
+                    bgr2hsv_inline(b, gg, r, hh, ss, vv);
+                    thr = work && in_range3(hh, ss, vv, rp);
+                }
+            } else {
+                thr = work && in_range3(0, 0, 0, a.rp);
+                if (mask2 != 0) {
+                    int hh, ss, vv;
+                    bgr2hsv_inline(b, gg, r, hh, ss, vv);
+                    thr = work && in_range3(hh, ss, vv, a.rp);
+                }
             }
         } else {
             thr = work && b >= a.rp.lo[0] && b <= a.rp.hi[0];
@@ -770,12 +837,13 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         AU_REC(svm, true);
         if (k >= 1 && k < nnew && __float_as_uint(pm.w[k]) != 0u) newcnt |= 1 << (kLiveShift + k);   // (bits: an imported -0.f is live)
     }
-    const bool sc = work && (newcnt != cnt || a.fresh);
+    const bool sc = work && (newcnt != cnt || fresh);
     if (sc) nmbase[coff] = (uint8_t)newcnt;
     AU_B(sc, true);
 
     const u64 word = __ballot(thr);
-    u64 *const thr_out = NF == 2 ? a.thr_bits2 : a.thr_bits;
+    if (kLate) KRELOAD(ka);
+    u64 *const thr_out = kLate ? (NF == 2 ? ka->thr_bits2 : ka->thr_bits) : NF == 2 ? a.thr_bits2 : a.thr_bits;
     if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
     au.run(thr_out && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
