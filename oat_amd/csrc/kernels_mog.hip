@@ -169,10 +169,17 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
 // nentry: mode count at entry (the reference's nNewModes).  Returns the foreground-mask value
 // {0, shadowVal, 255}; nmodes_out: the count to store; wchg: weights may differ from what was loaded
 // (false only when alpha == 0 and the renormalisation was by exactly 1).
+// shadow_matters (wave-uniform): whether anything downstream can tell shadowVal from 255.  detectShadowGMM only picks
+// the VALUE of a foreground pixel's mask entry; the model does not depend on it, and Oat keeps shadow and foreground
+// pixels alike (`frame.setTo(0, mask == 0)`, BackgroundSubtractorMOG.cpp:125).  Unless the caller asked for the mask
+// bytes (oatgpu_mog_apply / oatgpu_mog_filter's mask tap) or shadowVal is 0 -- a shadow pixel would then BE background --
+// the test is dead code: the fused path returns 255 for every foreground pixel without walking the modes.  (On a dense
+// model a few lanes of most waves leave the background and every wave walked detectShadowGMM's five modes for them:
+// ~500 of the streaming-load instantiation's 1 266 vector instructions a wave, profiles/r03n_dead_shadow_test.txt.)
 template <int CH, bool TUP>
 __device__ __forceinline__ int mog2_finish(PxModel<CH, TUP> &s, PxLoop &c, int nentry, int &nmodes_out, float x0, float x1,
                                            float x2, const MogParams &P, float alphaT, float alpha1, unsigned &dvm,
-                                           bool &wchg)
+                                           bool &wchg, bool shadow_matters)
 {
     int nmodes = c.nmodes;
     // renormalise
@@ -213,7 +220,7 @@ __device__ __forceinline__ int mog2_finish(PxModel<CH, TUP> &s, PxLoop &c, int n
 
     if (c.background) return 0;
     int mask = 255;
-    if (P.detectShadows) {
+    if (P.detectShadows && shadow_matters) {
         // detectShadowGMM
         float tW = 0.f;
         bool done = false;
@@ -590,6 +597,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     // allocator put it 12 bytes into scratch at its 72 registers)
     constexpr bool kSingle = NF == 1 || NTLD;
     const bool fresh = kSingle && a.fresh;
+    const bool shadow_matters = (kSingle && a.out_mask != nullptr) || a.mp.shadowVal == 0;       // (uniform; mog2_finish)
     if (!fresh) {
         cnt = nmbase[coff];
         pm.w[0] = LDW(0);
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
         CUT(3);                      // + modes 1..4 of frame 1
 #endif
-        mask = mog2_finish<CH, TUP>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg);
+        mask = mog2_finish<CH, TUP>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg, shadow_matters);
     }
 #ifdef OATGPU_CUT
     cut_extra_ = mask + nnew + dvm + (int)wchg;
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
             mog2_mode<CH, 2, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
             mog2_mode<CH, 3, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
             mog2_mode<CH, 4, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2);
+            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
         if (CH == 3) {
