@@ -943,6 +943,38 @@ def main():
         except Exception as e:
             log("one-frame-a-launch leg failed:", e)
 
+    # ---- the benched workload at Oat's DEFAULT learning rate, `framefilt mog` without -a (BackgroundSubtractorMOG.cpp:51-67,
+    # adaptation_coeff 0; SURVEY 8d: "and a second run at alpha = 0 = Oat default"): frame 1 learns at 1/2 (OpenCV's automatic
+    # rate), every later frame leaves the model as it is -- one mode a pixel, read-only: 3 + 1 + 20 B/px a frame ----
+    frozen = None
+    if solo and not args.no_extra and args.input == "device" and not args.dense_model and ALPHA != 0.0:
+        keep_alpha = ALPHA
+        try:
+            ALPHA = 0.0
+            l0 = Leg(args.workload, local_rank, rank, pool=args.pool)
+            o = timed_run(l0, K, max(W, 50), local_barrier(l0), 8, age_frames=60, export=not args.no_parity,
+                          spin=0.0 if args.no_spin_up else 0.2, spin_args=(args.workload, local_rank, rank))
+            f_k1 = k1_ms(o["prof"])[0]
+            f_fpl = o["prof"]["mog_frames"] / max(o["prof"]["steps"], 1)
+            f_aud = audit(l0, 4)
+            f_par = "skipped"
+            if not args.no_parity:
+                f_par, _ = gates(l0, o["gate_offset"], K, o["positions"], min(args.check_steps, 16), o["models"], o["handover"])
+            frozen = dict(value=ns * K / o["block_s"], unit="frames/s", learning_rate=0.0, steps=K, blocks=o["n_blocks"],
+                          ms_per_step=o["block_s"] / K * 1e3, k_mog_fused_ms=f_k1, frames_per_launch=f_fpl,
+                          useful_bytes_per_px=f_aud["useful_read_B_per_px"] + f_aud["useful_write_B_per_px"],
+                          audit_frames_per_launch=f_aud["frames_per_launch"], parity=f_par,
+                          note="Oat's default: oat framefilt mog without -a (adaptation_coeff 0): the first frame initialises "
+                               "the model, later frames only classify against it (one mode a pixel, nothing stored); same "
+                               "workload, same block timing, both parity gates at this rate")
+            l0.close()
+            del l0
+            torch.cuda.empty_cache()
+        except Exception as e:
+            log("default-learning-rate leg failed:", e)
+        finally:
+            ALPHA = keep_alpha
+
     total_streams = ns * world
     block_s = tr["block_s"]
     fps = total_streams * K / block_s
@@ -993,7 +1025,7 @@ def main():
                 del dl
                 torch.cuda.empty_cache()
                 # the same leg on an input whose pixels all STAY background (noise +-3 instead of +-5: no lane of any wave
-                # runs detectShadowGMM, ~400 vector instructions a wave in the leg above): the bytes without the extra arithmetic
+                # creates a mode, converts a foreground pixel to HSV or walks past its own mode): the bytes without the extra arithmetic
                 try:
                     keep_noise, DENSE_NOISE = DENSE_NOISE, 3
                     dq = Leg("4k1", local_rank, rank, dense=True, pool=10)
@@ -1118,9 +1150,10 @@ def main():
                 audited_sector_bytes_per_px=qa.get("sector32_read_B_per_px", 0) + qa.get("sector32_write_B_per_px", 0),
                 note="the dense leg with per-frame noise +-3 instead of +-5: every pixel still cycles through its five modes and "
                      "every lane loads and stores the whole model (audited bytes beside it), but no pixel leaves the background, "
-                     "so no wave runs detectShadowGMM.  In the +-5 leg that `frac` is quoted on, one or two lanes of most waves do "
-                     "(~400 vector instructions a wave, profiles/r03h_cut_profile.md) and the kernel is bound by the vector ALU "
-                     "(92 % busy), not by memory")
+                     "so no wave runs the no-fit paths.  In the +-5 leg that `frac` is quoted on, one or two lanes of most waves "
+                     "leave the background: their waves create a mode, walk all five and convert the pixel to HSV (1 005 against 562 "
+                     "vector instructions a wave, profiles/r03p_k1_sq_counters_dense.md; the shadow test, which nothing on the fused "
+                     "path can observe, is not evaluated since r03 -- DESIGN.md section 3)")
             roofline["frac_all_background"] = roofline["all_background"]["frac"]
         # the frame rate that belongs next to `frac`: whole chain on the dense model (one 4K stream)
         roofline["value_dense_fps"] = 1e3 / dense["ms_per_step"] if dense.get("ms_per_step") else None
@@ -1157,6 +1190,7 @@ def main():
         "metric": "frames/sec/GPU (1080p & 4K) mog+hsv+ccl fused; % HBM roofline",
         "value": fps,
         "value_one_frame_a_launch": one_frame["value"] if one_frame else None,
+        "value_default_learning_rate_0": frozen["value"] if frozen else None,
         "unit": "frames/s",
         "n_gpus": world,
         "steps": K,
@@ -1208,6 +1242,7 @@ def main():
     if solo and not args.no_extra and args.input == "device" and not args.dense_model:
         line["extra_workloads"] = extra
         line["one_frame_a_launch"] = one_frame
+        line["default_learning_rate_0"] = frozen
 
     line["pipeline"] = None
     if solo and not args.no_pipeline and args.input == "device" and not args.dense_model:

@@ -114,7 +114,7 @@ __device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &d
 // dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
 // 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
-template <int CH, int MODE, bool TUP>
+template <int CH, int MODE, bool TUP, bool FROZEN = false>
 __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
                                           float alphaT, float alpha1, float prune, unsigned &dvm)
 {
@@ -133,15 +133,27 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 fit_here = true;
                 weight += alphaT;
                 const float k = alphaT / weight;
-                set_rm<0>(s, MODE, rm<0>(s, MODE) - k * d0);
-                if (CH == 3) { set_rm<1>(s, MODE, rm<1>(s, MODE) - k * d1); set_rm<2>(s, MODE, rm<2>(s, MODE) - k * d2); }
+                const float o0 = rm<0>(s, MODE), o1 = CH == 3 ? rm<1>(s, MODE) : 0.f, o2 = CH == 3 ? rm<2>(s, MODE) : 0.f;
+                const float n0 = o0 - k * d0, n1 = CH == 3 ? o1 - k * d1 : 0.f, n2 = CH == 3 ? o2 - k * d2 : 0.f;
+                set_rm<0>(s, MODE, n0);
+                if (CH == 3) { set_rm<1>(s, MODE, n1); set_rm<2>(s, MODE, n2); }
                 float varnew = var + k * (dist2 - var);
                 // MAX(varnew, varMin) then MIN(.., varMax) of the reference's macros -- as v_max_f32 / v_min_f32: with a
                 // NaN on the left the macro yields the bound, and so does the instruction (the bounds are never NaN)
                 varnew = __builtin_fmaxf(varnew, P.varMin);
                 varnew = __builtin_fminf(varnew, P.varMax);
                 set_rv(s, MODE, varnew);
-                dvm |= (1u << MODE);
+                // The record goes back to memory when it was written.  At learning rate 0 -- Oat's default, a frozen model --
+                // k is 0 and the update leaves every bit as it was (unless the variance sat outside its clamp or the model
+                // holds non-finite values): only a record whose bits DID change is marked, so a frozen model is read-only
+                // (16 of the 43 B/px a two-frame launch moved at rate 0 were such stores).  FROZEN: the instantiations the
+                // launcher picks when every rate of the launch is 0 -- as a run-time test of the rate the compiler turned it
+                // into ~10 more vector instructions at every fit site of the launches that learn.
+                bool dirty = true;
+                if (FROZEN)
+                    dirty = __float_as_uint(n0) != __float_as_uint(o0) || __float_as_uint(n1) != __float_as_uint(o1) ||
+                            __float_as_uint(n2) != __float_as_uint(o2) || __float_as_uint(varnew) != __float_as_uint(var);
+                if (dirty) dvm |= (1u << MODE);
                 // The reference bubbles the OLD weight up and then stores the new one
                 // into the final slot; carrying the new weight along is the same state.
                 s.w[MODE] = weight;
@@ -422,9 +434,10 @@ __device__ __forceinline__ RangeParams karg_rp(KArgs ka)
     return r;
 }
 
-template <int CH, bool AUDIT, bool NTLD, int NF>
+template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
 __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
+    static_assert(!FROZEN || (!AUDIT && !NTLD), "the frozen-model instantiations exist for the default-policy product kernels only");
     // The audited two-frame instantiation exists for BGR only (GREY audits count one-frame launches: the library does
     // not pair GREY frames while an audit is on).  Round 2's "instantiation the compiler is touchy about" was the
     // wide-store data hazard of st_rec below, root-caused in round 3.
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     PxLoop lp{false, false, nold, 0.f};
     unsigned dvm = 0;           // modes whose variance/mean changed
     bool wchg = false;          // weights changed
-    if (valid) mog2_mode<CH, 0, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+    if (valid) mog2_mode<CH, 0, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
     // A pixel that matched mode 0 as background never looks at another mode's variance/mean again this
     // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
     // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
@@ -710,10 +723,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     CUT(2);                          // + phase 2 loads
     int mask = 0, nnew = nold;
     if (work) {
-        mog2_mode<CH, 1, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 2, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 3, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 4, TUP>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 1, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 2, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 3, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 4, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
 #ifdef OATGPU_CUT
         cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
         CUT(3);                      // + modes 1..4 of frame 1
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
         PxLoop lq{false, false, nold2, 0.f};
         bool wchg2 = false;
-        if (valid) mog2_mode<CH, 0, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+        if (valid) mog2_mode<CH, 0, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
         const bool full2 = valid && !(lq.fits && lq.background);
         if (!kEarly2) {
             // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
@@ -792,10 +805,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         }
         int mask2 = 0, nnew2 = nold2;
         if (work) {
-            mog2_mode<CH, 1, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 2, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 3, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 4, TUP>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 1, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 2, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 3, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 4, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
             mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
@@ -894,11 +907,11 @@ void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 
-template <int CH, bool AUDIT, bool NTLD, int NF>
+template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
 static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF>), grid, dim3(256), 0, st, g, a, first_stream);
+    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), 0, st, g, a, first_stream);
 }
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
@@ -909,6 +922,9 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n
         } else if (a.nt_loads) {
             if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st);
             else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st);
+        } else if (a.alphaT == 0.f && a.alphaT2 == 0.f) {      // a frozen model (Oat's default rate): mog2_mode, FROZEN
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st);
+            else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st);
         } else {
             if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st);
             else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st);
@@ -919,6 +935,9 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n
     } else if (a.nt_loads) {
         if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st);
         else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st);
+    } else if (a.alphaT == 0.f && !a.fresh) {
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st);
+        else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st);
     } else {
         if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st);
         else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st);
