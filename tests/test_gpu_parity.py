@@ -1240,6 +1240,45 @@ def test_two_frames_a_launch_equals_one_frame_a_launch(A, ch, restore, ring):
             assert _eq(a, b)          # every slot of every plane, live or not
 
 
+@pytest.mark.parametrize("fusion", [1, 2])
+def test_frozen_model_is_read_only_except_where_the_update_changes_bits(A, fusion):
+    """Learning rate 0 (Oat's default) runs K1's FROZEN instantiations: a fitted record goes back to memory only when the
+    update changed its bits.  With k = 0 it normally does not -- but a variance outside [varMin, varMax] is clamped, equal
+    weights still swap, and weights that do not sum to 1 are renormalised: an imported model with all three must come out
+    as the oracle's, masks and full model, through the synchronous and the pipelined (two frames a launch) path."""
+    rng = np.random.default_rng(77)
+    rows, cols = 41, 150
+    n = rows * cols
+    base = rng.integers(40, 200, (rows, cols, 3)).astype(np.int16)
+    frames = [np.clip(base + rng.integers(-4, 5, base.shape), 0, 255).astype(np.uint8) for _ in range(9)]
+    nm = np.full(n, 2, np.uint8)
+    w = np.zeros((n, 5), np.float32); w[:, 0] = 0.45; w[:, 1] = 0.45           # equal weights, sum 0.9
+    v = np.zeros((n, 5), np.float32); v[:, 0] = 100.0; v[:, 1] = 2.0            # outside the clamp [4, 75]
+    m = np.zeros((n, 5, 3), np.float32)
+    m[:, 0] = base.reshape(n, 3); m[:, 1] = 255 - base.reshape(n, 3)
+    third = np.arange(n) % 3 == 0                                              # a third of the pixels: everyday, in-range model
+    v[third, 0] = 15.0; w[third, 0] = 1.0; w[third, 1] = 0.0; nm[third] = 1; v[third, 1] = 0.0; m[third, 1] = 0.0
+    hp = A.HotPath(rows, cols, adaptation_coeff=0.0, dilate=3, ring_depth=4)
+    hp.set_fusion(fusion)
+    orc = O.Mog2(rows, cols)
+    hp.track([frames[0]]); orc.apply(frames[0], 0.0)                           # (a first frame: geometry, frame counter)
+    hp.set_mog_state(nm, w, v, m, 5)
+    orc.set_state(nm, w, v, m, 5)
+    if fusion == 1:
+        for f in frames[1:]:
+            hp.track([f])
+    else:
+        for f in frames[1:]:
+            hp.enqueue([f])
+        for _ in frames[1:]:
+            hp.collect()
+    for f in frames[1:]:
+        orc.apply(f, 0.0)
+    _same_state(hp.mog_state(), orc.state(), ("frozen", fusion))
+    gv = hp.mog_state()[2]
+    assert (gv[~third, 0] == 75.0).all() and (gv[third, 0] == 15.0).all()       # the clamp acted on the fitted mode, and was stored
+
+
 def test_two_frames_a_launch_with_changing_rates_and_early_collects(A):
     """The second frame of a launch carries its own learning rate (automatic 1/min(2n, history), fixed, 0, and >= 1 =
     re-initialise, which is never paired); collects that reach a frame still only registered send it off alone."""
