@@ -1258,7 +1258,7 @@ def test_frozen_model_is_read_only_except_where_the_update_changes_bits(A, fusio
     m[:, 0] = base.reshape(n, 3); m[:, 1] = 255 - base.reshape(n, 3)
     third = np.arange(n) % 3 == 0                                              # a third of the pixels: everyday, in-range model
     v[third, 0] = 15.0; w[third, 0] = 1.0; w[third, 1] = 0.0; nm[third] = 1; v[third, 1] = 0.0; m[third, 1] = 0.0
-    hp = A.HotPath(rows, cols, adaptation_coeff=0.0, dilate=3, ring_depth=4)
+    hp = A.HotPath(rows, cols, adaptation_coeff=0.0, dilate=3, ring_depth=8)
     hp.set_fusion(fusion)
     orc = O.Mog2(rows, cols)
     hp.track([frames[0]]); orc.apply(frames[0], 0.0)                           # (a first frame: geometry, frame counter)
