@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 5     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2) */
+#define OATGPU_ABI_VERSION 6     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged */
 
 enum {
     OATGPU_OK = 0,
@@ -297,6 +297,15 @@ int oatgpu_track_enqueue_dev(oatgpu_ctx *ctx, const void *frames_dev, double lea
  * until the matching oatgpu_track_collect returns. */
 int oatgpu_track_enqueue(oatgpu_ctx *ctx, const uint8_t *const *frames_host, int32_t n, double learning_rate);
 int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
+/* oatgpu_track_enqueue camera by camera, for components whose cameras do not deliver at the same instant:
+ * oatgpu_track_stage starts the H2D copy of ONE camera's frame of the NEXT frame set as soon as that camera has
+ * one (PositionDetector.cpp:63-75 waits for its one source; an N-camera component need not hold the link idle
+ * until the slowest of N has delivered); once every stream 0..n_streams-1 has been staged,
+ * oatgpu_track_enqueue_staged registers the set exactly as oatgpu_track_enqueue would have.  While a set is being
+ * staged oatgpu_track_input_consumed_stream(i) waits for stream i's own copy (any staged stream, any order).
+ * OATGPU_E_RING_FULL from the first oatgpu_track_stage of a set when ring_depth sets are outstanding. */
+int oatgpu_track_stage(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *frame_host);
+int oatgpu_track_enqueue_staged(oatgpu_ctx *ctx, double learning_rate);
 
 /* oatgpu_track_input_consumed blocks until every frame handed over so far has been read out of the caller's
  * buffers -- host frames (oatgpu_track_enqueue): their H2D copies are done; device frames
@@ -309,6 +318,14 @@ int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
  * registered -- oatgpu_set_fusion -- the call launches it; if its speculative back half declined the frame, the
  * call launches the global kernels on it and reports 0 until they are done.) */
 int oatgpu_track_input_consumed(oatgpu_ctx *ctx);
+/* The same for ONE camera stream of the latest oatgpu_track_enqueue: returns when frames_host[stream_ix] has been
+ * read (its H2D copy is done), so an N-camera component posts every SOURCE as its own frame leaves shared memory
+ * instead of after all N copies -- the frames travel one after the other over one PCIe link, and the upstream
+ * writers of the first cameras refill their segments while the later copies are still running (PositionDetector.cpp:78-86
+ * releases its one source right after its one memcpy; this is that rule per camera).  Call it for the streams in
+ * ascending order.  Per-stream events are recorded from the first call on (that first call waits for the whole
+ * set); for device frames it is oatgpu_track_input_consumed. */
+int oatgpu_track_input_consumed_stream(oatgpu_ctx *ctx, int32_t stream_ix);
 int oatgpu_track_ready(oatgpu_ctx *ctx);
 
 /* A whole recorded sequence through the pipelined path in one call (what `oat frameserve file`

@@ -350,6 +350,24 @@ class HotPath(_Context):
         (oatgpu_track_input_consumed): host frames copied, device frames read by their per-pixel kernel."""
         self._chk(self.lib.oatgpu_track_input_consumed(self.ctx))
 
+    def stage(self, stream, frame):
+        """oatgpu_track_stage: ONE camera's frame of the next frame set starts its H2D copy now."""
+        f = _frame(frame, self.frame_shape)
+        self._staged_keep = getattr(self, "_staged_keep", []) + [f]
+        self._chk(self.lib.oatgpu_track_stage(self.ctx, int(stream), ffi.u8(f)))
+
+    def enqueue_staged(self):
+        """oatgpu_track_enqueue_staged: every stream staged -> the set is registered like enqueue()."""
+        self._chk(self.lib.oatgpu_track_enqueue_staged(self.ctx, self.learning_coeff_))
+        self._held = getattr(self, "_held", [])
+        self._held.append(self._staged_keep)
+        self._staged_keep = []
+
+    def input_consumed_stream(self, stream):
+        """The frame of ONE camera stream of the latest enqueue() has left the caller's buffer
+        (oatgpu_track_input_consumed_stream; call for the streams in ascending order)."""
+        self._chk(self.lib.oatgpu_track_input_consumed_stream(self.ctx, int(stream)))
+
     def collect(self):
         self._chk(self.lib.oatgpu_track_collect(self.ctx, self._pos))
         if getattr(self, "_held", None):

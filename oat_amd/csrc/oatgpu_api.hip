@@ -74,6 +74,11 @@ struct oatgpu_ctx {
     hipStream_t stream_c = nullptr;  // H2D copies of oatgpu_track_enqueue (created on first use)
     uint8_t *frames_ring = nullptr;  // [ring_slots][n_streams*rows*cols*channels] staging for host frames
     std::vector<hipEvent_t> copy_ev; // [ring_slots] frames of this slot have arrived
+    std::vector<hipEvent_t> copy_ev_s;   // [ring_slots][n_streams] ... and every single one of them (oatgpu_track_input_consumed_stream)
+    std::vector<char> staged;            // [n_streams] oatgpu_track_stage: frame of the NEXT set already on its way
+    int staged_count = 0, stage_slot = -1;
+    bool per_stream_copy_ev = false;     // recorded from the first per-stream call on
+    bool last_copy_per_stream = false;   // the latest enqueue recorded them
     int last_copy_slot = -1;         // slot of the most recent oatgpu_track_enqueue (host frames)
     KalmanLaunch kal{};              // kal.state == nullptr: position filter off
     bool kal_on = false;
@@ -329,6 +334,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     for (auto e : c->copy_ev) hipEventDestroy(e);
+    for (auto e : c->copy_ev_s) hipEventDestroy(e);
     for (auto &b : c->bb) {
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
@@ -1064,6 +1070,70 @@ extern "C" int oatgpu_track_enqueue_dev(oatgpu_ctx *c, const void *frames_dev, d
     return rc;
 }
 
+// device staging ring + copy stream of the host-frame path (first use)
+static int ensure_host_ring(oatgpu_ctx *c)
+{
+    if (c->frames_ring) return OATGPU_OK;
+    const size_t sb = (size_t)c->g.H * c->g.W * c->cfg.channels * c->cfg.n_streams;
+    if (c->private_streams) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    else c->stream_c = acquire_copy_stream(c->cfg.device);
+    if (!c->stream_c) return fail(c, OATGPU_E_HIP, "could not create the copy stream");
+    HIPCHK(c, hipMalloc((void **)&c->frames_ring, sb * c->ring_slots));
+    c->copy_ev.resize(c->ring_slots);
+    for (auto &e : c->copy_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    return OATGPU_OK;
+}
+static int ensure_stream_events(oatgpu_ctx *c)
+{
+    if (!c->copy_ev_s.empty()) return OATGPU_OK;
+    c->copy_ev_s.resize((size_t)c->ring_slots * c->cfg.n_streams);
+    for (auto &e : c->copy_ev_s) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    return OATGPU_OK;
+}
+
+// The host-frame path camera by camera: oatgpu_track_stage starts ONE camera's H2D copy into the next frame set's
+// staging slot; when all n_streams are on their way oatgpu_track_enqueue_staged registers the set exactly as
+// oatgpu_track_enqueue would have.
+extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_t *frame_host)
+{
+    if (!c || !frame_host) return fail(c, OATGPU_E_INVALID, "null argument");
+    const int n = c->cfg.n_streams;
+    if (stream_ix < 0 || stream_ix >= n) return fail(c, OATGPU_E_INVALID, "stream index %d out of range", stream_ix);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->staged_count == 0) {
+        if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
+        { const int rc = ensure_host_ring(c); if (rc) return rc; }
+        { const int rc = ensure_stream_events(c); if (rc) return rc; }
+        c->staged.assign((size_t)n, 0);
+        c->stage_slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
+    }
+    if (c->staged[(size_t)stream_ix]) return fail(c, OATGPU_E_INVALID, "stream %d is already staged for this frame set", stream_ix);
+    const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels;
+    uint8_t *dst = c->frames_ring + (size_t)c->stage_slot * fb * n;
+    HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, c->stream_c));
+    HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)c->stage_slot * n + stream_ix], c->stream_c));
+    c->staged[(size_t)stream_ix] = 1;
+    c->staged_count++;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_track_enqueue_staged(oatgpu_ctx *c, double lr)
+{
+    if (!c) return OATGPU_E_INVALID;
+    const int n = c->cfg.n_streams;
+    if (c->staged_count != n) return fail(c, OATGPU_E_INVALID, "%d of %d streams staged", c->staged_count, n);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int slot = c->stage_slot;
+    const size_t sb = (size_t)c->g.H * c->g.W * c->cfg.channels * n;
+    HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
+    c->last_copy_slot = slot;
+    c->last_copy_per_stream = true;
+    c->per_stream_copy_ev = true;
+    c->staged_count = 0;
+    const int rc = enqueue_frames(c, c->frames_ring + (size_t)slot * sb, lr, c->copy_ev[slot]);
+    return rc;
+}
+
 extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_host, int32_t n, double lr)
 {
     if (!c || !frames_host) return fail(c, OATGPU_E_INVALID, "null argument");
@@ -1072,21 +1142,19 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
     for (int s = 0; s < n; ++s) if (!frames_host[s]) return fail(c, OATGPU_E_INVALID, "null frame %d", s);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels, sb = fb * n;
-    if (!c->frames_ring) {
-        if (c->private_streams) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
-        else c->stream_c = acquire_copy_stream(c->cfg.device);
-        if (!c->stream_c) return fail(c, OATGPU_E_HIP, "could not create the copy stream");
-        HIPCHK(c, hipMalloc((void **)&c->frames_ring, sb * c->ring_slots));
-        c->copy_ev.resize(c->ring_slots);
-        for (auto &e : c->copy_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
-    }
+    if (c->staged_count) return fail(c, OATGPU_E_INVALID, "a frame set is being staged (oatgpu_track_stage): finish it with oatgpu_track_enqueue_staged");
+    { const int rc = ensure_host_ring(c); if (rc) return rc; }
     // the slot's staging buffer was last read by the K1 of the frame collected from this slot
     const int slot = (int)(c->enq_total % (unsigned long long)c->ring_slots);
     uint8_t *dst = c->frames_ring + (size_t)slot * sb;
-    for (int s = 0; s < n; ++s)
+    if (c->per_stream_copy_ev) { const int rc = ensure_stream_events(c); if (rc) return rc; }
+    for (int s = 0; s < n; ++s) {
         HIPCHK(c, hipMemcpyAsync(dst + (size_t)s * fb, frames_host[s], fb, hipMemcpyHostToDevice, c->stream_c));
+        if (c->per_stream_copy_ev && s + 1 < n) HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)slot * n + s], c->stream_c));
+    }
     HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
     c->last_copy_slot = slot;
+    c->last_copy_per_stream = c->per_stream_copy_ev;
     return enqueue_frames(c, dst, lr, c->copy_ev[slot]);
 }
 
@@ -1369,6 +1437,35 @@ extern "C" int oatgpu_track_input_consumed(oatgpu_ctx *c)
     }
     if (c->last_copy_slot < 0) return OATGPU_OK;
     HIPCHK(c, hipEventSynchronize(c->copy_ev[c->last_copy_slot]));
+    return OATGPU_OK;
+}
+
+// A copy of one frame takes ~0.1 ms; hipEventSynchronize puts the thread to sleep and its wake-up costs 30-50 us -- a
+// third of the wait, once per camera and round.  Poll for up to 2 ms, then sleep.
+static hipError_t wait_short(hipEvent_t e)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(e);
+    }
+}
+
+extern "C" int oatgpu_track_input_consumed_stream(oatgpu_ctx *c, int32_t stream_ix)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (stream_ix < 0 || stream_ix >= c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "stream index %d out of range", stream_ix);
+    if (c->staged_count) {                                // a set being staged: that camera's own copy
+        if (!c->staged[(size_t)stream_ix]) return fail(c, OATGPU_E_INVALID, "stream %d is not staged", stream_ix);
+        HIPCHK(c, wait_short(c->copy_ev_s[(size_t)c->stage_slot * c->cfg.n_streams + stream_ix]));
+        return OATGPU_OK;
+    }
+    c->per_stream_copy_ev = true;                         // from the next enqueue on
+    // device frames, a set enqueued before the switch, the last stream of a set: the whole set's rule
+    if (c->dev_unconsumed || c->last_copy_slot < 0 || !c->last_copy_per_stream || stream_ix + 1 == c->cfg.n_streams)
+        return oatgpu_track_input_consumed(c);
+    HIPCHK(c, wait_short(c->copy_ev_s[(size_t)c->last_copy_slot * c->cfg.n_streams + stream_ix]));
     return OATGPU_OK;
 }
 

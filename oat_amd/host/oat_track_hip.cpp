@@ -12,8 +12,8 @@
 //
 //   wait on every SOURCE                              PositionDetector.cpp:63-75
 //   oatgpu_track_enqueue(frames in shared memory)     the H2D copies read the (page-locked) shm frames
-//   oatgpu_track_input_consumed, post every SOURCE    the reference posts right after its memcpy (:78-86);
-//                                                     here right after the DMA out of the segment
+//   oatgpu_track_input_consumed_stream(i), post SOURCE i   the reference posts right after its memcpy (:78-86);
+//                                                     here, camera by camera, right after the DMA out of its segment
 //   collect + publish finished results                :88-96, SINK i: wait, *shared = position, post
 //
 // A result is published as soon as it is ready when no new frame is waiting (minimum latency, camera-bound
@@ -177,23 +177,36 @@ protected:
 
     int process() override
     {
-        // ---- a frame from every camera (PositionDetector.cpp:63-75) ----
+        // ---- a frame from every camera (PositionDetector.cpp:63-75), camera by camera: as soon as camera s has delivered,
+        // its H2D copy starts (oatgpu_track_stage), and camera s - 1, whose copy has meanwhile left its segment, is
+        // posted (PositionDetector.cpp:78-86 per camera) -- the n frames cross one PCIe link one after the other, and
+        // the upstream writers refill their segments while the later cameras are still being waited for and copied
+        // (8 x 1080p: a round is the link's time, not the slowest writer's memcpy + the link's time) ----
         std::vector<Sample> samples(n_);
         for (int s = 0; s < n_; ++s) {
             if (frame_sources_[s].wait() == NodeState::END) {
-                for (int q = 0; q < s; ++q) frame_sources_[q].post();     // hand back what was taken this round
-                while (!pending_.empty() && !quit) publish();             // every frame already taken still gets its token
+                // (frames of this round already staged are dropped with the round: their sources get their post, the
+                // set is never registered; frames of earlier rounds still get their tokens)
+                for (int q = (s > 0 ? s - 1 : 0); q < s; ++q) {
+                    gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, q));
+                    frame_sources_[q].post();
+                }
+                while (!pending_.empty() && !quit) publish();
                 return 1;
             }
             const Frame &shm = *frame_sources_[s].retrieve();
             src_pins_[s].pin(shm);
-            frame_ptrs_[s] = shm.data();
             samples[s] = shm.sample();
+            gpu_.check(oatgpu_track_stage(gpu_.ctx, s, shm.data()));
+            if (s > 0) {
+                gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, s - 1));
+                frame_sources_[s - 1].post();
+            }
         }
-        gpu_.check(oatgpu_track_enqueue(gpu_.ctx, frame_ptrs_.data(), n_, learning_coeff_));
+        gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, n_ - 1));
+        frame_sources_[n_ - 1].post();
+        gpu_.check(oatgpu_track_enqueue_staged(gpu_.ctx, learning_coeff_));
         pending_.push_back(std::move(samples));
-        gpu_.check(oatgpu_track_input_consumed(gpu_.ctx));                // the DMA has left the segments ...
-        for (int s = 0; s < n_; ++s) frame_sources_[s].post();            // ... upstream may write the next frames
 
         // ---- results: as early as possible when no camera has a frame waiting, otherwise when the ring is full ----
         while (!pending_.empty() && !quit) {

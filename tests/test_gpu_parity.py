@@ -1129,6 +1129,67 @@ def test_track_ready_and_input_consumed(A):
         assert hp.collect() == ref.track(frames), t
 
 
+def test_input_consumed_per_stream(A):
+    """oatgpu_track_input_consumed_stream: an N-camera component posts SOURCE i as soon as frame i has left its buffer.  After
+    the call for stream i the host buffer of stream i (and of every stream before it) may be overwritten; the first
+    call falls back to the whole set and switches the per-stream events on; out-of-range indices are refused."""
+    rows, cols, n = 96, 200, 3
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    kw = dict(n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+    hp = A.HotPath(rows, cols, ring_depth=3, **kw)
+    ref = A.HotPath(rows, cols, **kw)
+    streams = [SyntheticStream(rows, cols, 60 + s, n_discs=1, radius=9) for s in range(n)]
+    bufs = [np.empty((rows, cols, 3), np.uint8) for _ in range(n)]
+    assert hp.lib.oatgpu_track_input_consumed_stream(hp.ctx, n) < 0 and hp.lib.oatgpu_track_input_consumed_stream(hp.ctx, -1) < 0
+    for t in range(10):
+        frames = [st.frame(t, with_discs=t > 0) for st in streams]
+        for b, f in zip(bufs, frames):
+            b[...] = f
+        hp.enqueue(bufs)
+        for s_ in range(n):
+            hp.input_consumed_stream(s_)
+            bufs[s_][...] = 255 - bufs[s_]                            # scribble at once: this frame must be on the device
+        assert hp.collect() == ref.track(frames), t
+
+
+def test_stage_camera_by_camera_equals_enqueue(A):
+    """oatgpu_track_stage / oatgpu_track_enqueue_staged: the host-frame path camera by camera (any order, each camera's
+    buffer reusable after its own input_consumed_stream) gives what oatgpu_track_enqueue gives; a set cannot be
+    registered before it is complete, a stream cannot be staged twice, and enqueue() is refused while a set is open."""
+    rows, cols, n = 90, 170, 3
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    kw = dict(n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+    hp = A.HotPath(rows, cols, ring_depth=2, **kw)
+    ref = A.HotPath(rows, cols, **kw)
+    streams = [SyntheticStream(rows, cols, 80 + s, n_discs=1, radius=9) for s in range(n)]
+    bufs = [np.empty((rows, cols, 3), np.uint8) for _ in range(n)]
+    want = []
+    for t in range(9):
+        frames = [st.frame(t, with_discs=t > 0) for st in streams]
+        want.append(ref.track(frames))
+        order = [(t + k) % n for k in range(n)]
+        for k, s_ in enumerate(order):
+            bufs[s_][...] = frames[s_]
+            hp.stage(s_, bufs[s_])
+            if k == 0:
+                assert hp.lib.oatgpu_track_stage(hp.ctx, s_, A.ffi.u8(bufs[s_])) < 0          # twice
+                assert hp.lib.oatgpu_track_enqueue_staged(hp.ctx, 0.01) < 0                  # incomplete
+                ptrs = (A.ffi._u8p * n)(*[A.ffi.u8(b) for b in bufs])
+                assert hp.lib.oatgpu_track_enqueue(hp.ctx, ptrs, n, 0.01) < 0                # a set is open
+            hp.input_consumed_stream(s_)
+            bufs[s_][...] = 7                                         # scribble: the frame is on the device
+        hp.enqueue_staged()
+        if t % 2 == 1:                                               # ring of two: collect in pairs
+            assert hp.collect() == want[t - 1], t - 1
+            assert hp.collect() == want[t], t
+    assert hp.collect() == want[8]
+    hp.stage(0, bufs[0])                                             # ring empty again: a third set may start ...
+    hp.stage(1, bufs[1]); hp.stage(2, bufs[2]); hp.enqueue_staged()
+    hp.stage(0, bufs[0]); hp.stage(1, bufs[1]); hp.stage(2, bufs[2]); hp.enqueue_staged()
+    assert hp.lib.oatgpu_track_stage(hp.ctx, 0, A.ffi.u8(bufs[0])) == A.ffi.E_RING_FULL      # ... and the ring limit holds
+    hp.collect(); hp.collect()
+
+
 def test_back_half_speculation_and_repair(A):
     """The pipelined path launches the row scan + the single-workgroup LDS blob kernel only, as long as frames are
     sparse enough for it; a frame that is not (here: thousands of foreground specks) comes back marked and

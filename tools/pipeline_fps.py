@@ -21,6 +21,23 @@ sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "build", "bin")
 
 
+def node_pin(node):
+    """preexec_fn: the child runs on the CPUs of NUMA node `node` (its first-touch allocations land there)."""
+    if node == -2:
+        from oat_amd import ffi
+        node = ffi.load().oatgpu_device_numa_node(0)
+    if node is None or node < 0:
+        return None
+    try:
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    except OSError:
+        return None
+    return lambda: os.sched_setaffinity(0, cpus)
+
+
 def batched(a):
     from oat_amd.synth import SyntheticStream
     tag = "oat_p_" + uuid.uuid4().hex[:6]
@@ -43,7 +60,7 @@ def batched(a):
     time.sleep(4.0)
     t0 = time.perf_counter()
     feeders = [subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", raws[s], "--rows", str(a.rows), "--cols",
-                                 str(a.cols), "-n", str(a.frames)]) for s in range(n)]
+                                 str(a.cols), "-n", str(a.frames)], preexec_fn=node_pin(a.feeder_node)) for s in range(n)]
     tokens = ok = 0
     for r in readers:
         r.wait(timeout=300)
@@ -73,6 +90,9 @@ def main():
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--cameras", type=int, default=1)
     ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--feeder-node", type=int, default=-1,
+                    help="keep the frame servers (and so, by first touch, the shared-memory frames) on the CPUs of this NUMA "
+                         "node; -2 = the node GPU 0 hangs off (oatgpu_device_numa_node)")
     a = ap.parse_args()
     if a.cameras > 1:
         return batched(a)
