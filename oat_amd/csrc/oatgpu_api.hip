@@ -1309,6 +1309,8 @@ static int flush_pending(oatgpu_ctx *c)
 static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready)
 {
     if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
+    // (a set being staged owns the next ring slot: nothing else may be enqueued until oatgpu_track_enqueue_staged took it)
+    if (c->staged_count) return fail(c, OATGPU_E_INVALID, "a frame set is being staged (oatgpu_track_stage): finish it with oatgpu_track_enqueue_staged");
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     oatgpu_ctx::FrameJob cur;
