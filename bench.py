@@ -31,6 +31,7 @@ The PMC numbers come from rocprofv3 child processes of this very run (--no-pmc t
 import argparse
 import json
 import os
+import re
 import platform
 import shutil
 import sqlite3
@@ -760,6 +761,19 @@ def pipeline_block(device):
                  "sink.post() of the frame to the arrival of its position token, 1000 frames of 1920 x 1080 BGR in shared memory; "
                  "free_running = frames as fast as the tracker takes them (the tracker holds two in flight), paced = a 500 fps camera",
             **lat)
+        # configs[3]'s per-GPU shard from the drop-in boundary: 8 free-running 1080p cameras -> ONE batched oat-track-hip
+        # (camera-by-camera staging, ABI 6) -> 8 readers; aggregate rate incl. process start-up (tools/pipeline_fps.py)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipeline_fps.py"), "--rows", "1080", "--cols", "1920",
+                                "--frames", "1200", "--fused", "--cameras", "8", "--ring", "4"], capture_output=True, text=True, timeout=180)
+            m = re.search(r"(\d+) tokens in ([0-9.]+) s = ([0-9.]+) fps aggregate", r.stdout)
+            out["track_8x1080p"] = (dict(fps_aggregate=float(m.group(3)), tokens=int(m.group(1)), real_s=float(m.group(2)),
+                                         what="8 oat-frameserve-raw (free-running, 1200 frames each) -> one oat-track-hip with 8 SOURCEs "
+                                              "and 8 SINKs, ring 4 -> 8 oat-posi-cout; wall clock from the start of the frame servers "
+                                              "to the last token, process start-up included")
+                                    if m else dict(error=(r.stdout + r.stderr)[-200:]))
+        except Exception as e:
+            out["track_8x1080p"] = dict(error=str(e)[-200:])
     except Exception as e:
         out["error"] = str(e)[-300:]
     finally:
