@@ -75,6 +75,8 @@ struct oatgpu_ctx {
     uint8_t *frames_ring = nullptr;  // [ring_slots][n_streams*rows*cols*channels] staging for host frames
     std::vector<hipEvent_t> copy_ev; // [ring_slots] frames of this slot have arrived
     std::vector<hipEvent_t> copy_ev_s;   // [ring_slots][n_streams] ... and every single one of them (oatgpu_track_input_consumed_stream)
+    hipStream_t stream_c2 = nullptr;     // second copy stream of the camera-by-camera path (shared per device)
+    hipEvent_t ev_c2 = nullptr;          // ... and its "all my copies of this set are done"
     std::vector<char> staged;            // [n_streams] oatgpu_track_stage: frame of the NEXT set already on its way
     int staged_count = 0, stage_slot = -1;
     bool per_stream_copy_ev = false;     // recorded from the first per-stream call on
@@ -240,7 +242,7 @@ static MogParams mogparams_of(const oatgpu_config &k)
 namespace {
 struct DeviceStreams {
     int refs = 0, nb = 0;
-    hipStream_t a = nullptr, b[oatgpu_ctx::kNB] = {}, copy = nullptr;
+    hipStream_t a = nullptr, b[oatgpu_ctx::kNB] = {}, copy = nullptr, copy2 = nullptr;
     std::vector<hipStream_t> padding;
 };
 std::mutex g_streams_mutex;
@@ -299,6 +301,15 @@ bool acquire_streams(int device, int nb, hipStream_t *a, hipStream_t *b)
     for (int q = 0; q < nb; ++q) b[q] = d.b[q];
     return true;
 }
+// A second copy stream (created on first use: the camera-by-camera path alternates between the two, so that one copy's
+// set-up and completion signalling hide behind the other's transfer)
+hipStream_t acquire_copy_stream2(int device)
+{
+    std::lock_guard<std::mutex> lk(g_streams_mutex);
+    DeviceStreams &d = g_streams[device];
+    if (!d.copy2 && hipStreamCreateWithFlags(&d.copy2, hipStreamNonBlocking) != hipSuccess) d.copy2 = nullptr;
+    return d.copy2;
+}
 hipStream_t acquire_copy_stream(int device)
 {
     std::lock_guard<std::mutex> lk(g_streams_mutex);
@@ -333,6 +344,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->audit_dev);
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_c2) hipEventDestroy(c->ev_c2);
     for (auto e : c->copy_ev) hipEventDestroy(e);
     for (auto e : c->copy_ev_s) hipEventDestroy(e);
     for (auto &b : c->bb) {
@@ -1110,8 +1122,13 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
     if (c->staged[(size_t)stream_ix]) return fail(c, OATGPU_E_INVALID, "stream %d is already staged for this frame set", stream_ix);
     const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels;
     uint8_t *dst = c->frames_ring + (size_t)c->stage_slot * fb * n;
-    HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, c->stream_c));
-    HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)c->stage_slot * n + stream_ix], c->stream_c));
+    if (!c->stream_c2 && n > 1 && !c->private_streams) {
+        c->stream_c2 = acquire_copy_stream2(c->cfg.device);
+        if (c->stream_c2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    hipStream_t cs = (c->stream_c2 && (c->staged_count & 1)) ? c->stream_c2 : c->stream_c;
+    HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)c->stage_slot * n + stream_ix], cs));
     c->staged[(size_t)stream_ix] = 1;
     c->staged_count++;
     return OATGPU_OK;
@@ -1125,6 +1142,10 @@ extern "C" int oatgpu_track_enqueue_staged(oatgpu_ctx *c, double lr)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int slot = c->stage_slot;
     const size_t sb = (size_t)c->g.H * c->g.W * c->cfg.channels * n;
+    if (c->stream_c2) {                                   // the set is complete when BOTH copy streams are through
+        HIPCHK(c, hipEventRecord(c->ev_c2, c->stream_c2));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_c, c->ev_c2, 0));
+    }
     HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
     c->last_copy_slot = slot;
     c->last_copy_per_stream = true;
