@@ -14,14 +14,18 @@
 //     with -ffp-contract=off: every mul/add rounds on its own, like the
 //     reference's x86-64 build); the mixture lives in registers with fully
 //     unrolled, statically indexed mode loops (no scratch).
-//   * BGR->HSV uses the same integer tables as RGB2HSV_b, built once per block
-//     in LDS.
+//   * BGR->HSV uses RGB2HSV_b's integer quotients, taken on the spot by foreground lanes only
+//     (a zeroed pixel is HSV (0,0,0): one uniform window test); the stand-alone conversion
+//     kernel builds the two tables once per block in LDS.
+//   * what nothing on the fused path can observe is not computed (detectShadowGMM: mog2_finish),
+//     what did not change is not stored (a frozen model is read-only: FROZEN), and what is
+//     only needed late is loaded late (kernel arguments: KRELOAD).
 //   * the model is sparse in practice and the kernel moves only what the arithmetic can
 //     depend on, in TWO load phases: (1) counter byte + mode 0 + the pixel, for every lane;
 //     then the loop's mode-0 iteration runs, which tells whether the pixel matched mode 0 as
 //     background; (2) of slots 1..n-1: the weight of LIVE slots (non-zero weight, hinted in
 //     the counter byte), and variance/mean only on lanes that did NOT match ("needy": only
-//     they can test, revive or overwrite a later mode, or run the shadow test).  Stores go
+//     they can test, revive or overwrite a later mode).  Stores go
 //     out only for planes whose bits changed.  The state in HBM stays bit-identical to
 //     updating all of it (state-parity tests).
 #include "oatgpu_internal.h"
