@@ -1407,6 +1407,18 @@ static int repair_outstanding(oatgpu_ctx *c)
     return OATGPU_OK;
 }
 
+// A copy of one frame takes ~0.1 ms; hipEventSynchronize puts the thread to sleep and its wake-up costs 30-50 us -- a
+// third of the wait, once per camera and round.  Poll for up to 2 ms, then sleep.
+static hipError_t wait_short(hipEvent_t e)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(e);
+    }
+}
+
 extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
 {
     if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
@@ -1416,6 +1428,7 @@ extern "C" int oatgpu_track_collect(oatgpu_ctx *c, oatgpu_position *out)
         const int frc = flush_pending(c);
         if (frc) return frc;
     }
+    // (polling here, as wait_short does for the copies, made the one-camera latency WORSE: p50 207 -> 257 us free-running)
     HIPCHK(c, hipEventSynchronize(c->ring_ev[c->slot_ev[slot]]));
     const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
     if (!c->slot_repair[slot] && slot_needs_global(c, slot)) {
@@ -1461,18 +1474,6 @@ extern "C" int oatgpu_track_input_consumed(oatgpu_ctx *c)
     if (c->last_copy_slot < 0) return OATGPU_OK;
     HIPCHK(c, hipEventSynchronize(c->copy_ev[c->last_copy_slot]));
     return OATGPU_OK;
-}
-
-// A copy of one frame takes ~0.1 ms; hipEventSynchronize puts the thread to sleep and its wake-up costs 30-50 us -- a
-// third of the wait, once per camera and round.  Poll for up to 2 ms, then sleep.
-static hipError_t wait_short(hipEvent_t e)
-{
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t q = hipEventQuery(e);
-        if (q != hipErrorNotReady) return q;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(e);
-    }
 }
 
 extern "C" int oatgpu_track_input_consumed_stream(oatgpu_ctx *c, int32_t stream_ix)
