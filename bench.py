@@ -764,8 +764,18 @@ def pipeline_block(device):
         # configs[3]'s per-GPU shard from the drop-in boundary: 8 free-running 1080p cameras -> ONE batched oat-track-hip
         # (camera-by-camera staging, ABI 6) -> 8 readers; aggregate rate incl. process start-up (tools/pipeline_fps.py)
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipeline_fps.py"), "--rows", "1080", "--cols", "1920",
-                                "--frames", "1200", "--fused", "--cameras", "8", "--ring", "4"], capture_output=True, text=True, timeout=180)
+            # (its own process group: on a timeout the frame servers, the tracker and the readers go with it)
+            pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "pipeline_fps.py"), "--rows", "1080", "--cols", "1920",
+                                   "--frames", "1200", "--fused", "--cameras", "8", "--ring", "4"], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = pr.communicate(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                so, se = pr.communicate()
+                se = "timeout; " + (se or "")
+            r = argparse.Namespace(stdout=so or "", stderr=se or "")
             m = re.search(r"(\d+) tokens in ([0-9.]+) s = ([0-9.]+) fps aggregate", r.stdout)
             out["track_8x1080p"] = (dict(fps_aggregate=float(m.group(3)), tokens=int(m.group(1)), real_s=float(m.group(2)),
                                          what="8 oat-frameserve-raw (free-running, 1200 frames each) -> one oat-track-hip with 8 SOURCEs "
