@@ -47,6 +47,17 @@ def test_full_size_default_path_whole_model(A):
     assert state_check.run(1080, 1920, 40, 12, streams=16, audited=0, log=msgs.append) == 0, msgs
 
 
+def test_full_size_frozen_model(A):
+    """Oat's default learning rate (framefilt mog without -a: adaptation_coeff 0) at full HD through the pipelined path: the
+    FROZEN instantiations of the per-pixel kernel (records are stored only when their bits changed), two frames a launch
+    and one, whole model and every position against the oracle -- what bench.py's value_default_learning_rate_0 runs."""
+    _tools()
+    import state_check
+    msgs = []
+    assert state_check.run(1080, 1920, 41, 12, alpha=0.0, audited=0, log=msgs.append) == 0, msgs
+    assert state_check.run(1080, 1920, 21, 12, alpha=0.0, audited=0, fusion=1, log=msgs.append) == 0, msgs
+
+
 def test_single_launch_audited_equals_product(A):
     """The round-2 fault, isolated (tools/k1_fault_probe.py): from one exported model, ONE audited launch must leave
     exactly what ONE product launch leaves (and what the oracle leaves), with two frames a launch and with one,
