@@ -118,7 +118,7 @@ __device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &d
 // dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
 // 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
-template <int CH, int MODE, bool TUP, bool FROZEN = false>
+template <int CH, int MODE, bool TUP, int FROZEN = 0>        // FROZEN: 0 a launch that learns, 1 every rate of the launch is 0, 2 ask alphaT
 __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
                                           float alphaT, float alpha1, float prune, unsigned &dvm)
 {
@@ -153,8 +153,9 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 // (16 of the 43 B/px a two-frame launch moved at rate 0 were such stores).  FROZEN: the instantiations the
                 // launcher picks when every rate of the launch is 0 -- as a run-time test of the rate the compiler turned it
                 // into ~10 more vector instructions at every fit site of the launches that learn.
+                // (2: the traffic-audit instantiations, which must count what the product kernel of the same launch moves)
                 bool dirty = true;
-                if (FROZEN)
+                if (FROZEN == 1 || (FROZEN == 2 && alphaT == 0.f))
                     dirty = __float_as_uint(n0) != __float_as_uint(o0) || __float_as_uint(n1) != __float_as_uint(o1) ||
                             __float_as_uint(n2) != __float_as_uint(o2) || __float_as_uint(varnew) != __float_as_uint(var);
                 if (dirty) dvm |= (1u << MODE);
@@ -442,6 +443,7 @@ template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
 __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     static_assert(!FROZEN || (!AUDIT && !NTLD), "the frozen-model instantiations exist for the default-policy product kernels only");
+    constexpr int kFrozenMode = AUDIT ? 2 : FROZEN ? 1 : 0;
     // The audited two-frame instantiation exists for BGR only (GREY audits count one-frame launches: the library does
     // not pair GREY frames while an audit is on).  Round 2's "instantiation the compiler is touchy about" was the
     // wide-store data hazard of st_rec below, root-caused in round 3.
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     PxLoop lp{false, false, nold, 0.f};
     unsigned dvm = 0;           // modes whose variance/mean changed
     bool wchg = false;          // weights changed
-    if (valid) mog2_mode<CH, 0, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+    if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
     // A pixel that matched mode 0 as background never looks at another mode's variance/mean again this
     // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
     // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
@@ -727,10 +729,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     CUT(2);                          // + phase 2 loads
     int mask = 0, nnew = nold;
     if (work) {
-        mog2_mode<CH, 1, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 2, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 3, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 4, TUP, FROZEN>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
 #ifdef OATGPU_CUT
         cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
         CUT(3);                      // + modes 1..4 of frame 1
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
         PxLoop lq{false, false, nold2, 0.f};
         bool wchg2 = false;
-        if (valid) mog2_mode<CH, 0, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+        if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
         const bool full2 = valid && !(lq.fits && lq.background);
         if (!kEarly2) {
             // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
@@ -809,10 +811,10 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
         }
         int mask2 = 0, nnew2 = nold2;
         if (work) {
-            mog2_mode<CH, 1, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 2, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 3, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 4, TUP, FROZEN>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
             mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
