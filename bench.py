@@ -25,7 +25,9 @@ What the one JSON line carries besides the contract's keys (N = 1 only, rank 0):
                   benched (sparse) workload: frac_real (PMC bytes / kernel time), useful / moved B/px and
                   the waste ratio from the kernel's own traffic audit
     cpu_baseline  the oracle chain (a port of the reference's CPU path) on this host's cores
-    extra_workloads  1080p16 and 1080p1 measured the same way (shorter runs)
+    extra_workloads  1080p16, 1080p8, 1080p1 and vga1 measured the same way (shorter runs)
+    partition     N > 1: which global streams every rank owned, and every rank's own gate verdicts (both parity gates
+                  run on EVERY rank for every stream of its shard)
 The PMC numbers come from rocprofv3 child processes of this very run (--no-pmc to skip them).
 """
 import argparse
@@ -129,9 +131,12 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
+THREAD_SHARE = 1                # ranks of this job on this host (N > 1: every rank runs its own gates; they share the cores)
+
+
 def host_threads():
     # the port's row workers are a persistent pool since r03 (oracle/pool.c): one per physical core
-    return max(1, min(physical_cores(), 256))
+    return max(1, min(physical_cores() // max(THREAD_SHARE, 1), 256))
 
 
 def parity_gate(wl, device, frames_seq):
@@ -206,27 +211,61 @@ def cpu_time_chain(wl, frames_seq, nthreads, budget_s, max_frames):
     return n / el, n, el
 
 
+def cpu_time_pipeline(wl, frames_seq, t_front, t_mid, pipelined, budget_s, max_frames):
+    """frames/s of the oracle chain through oracle/pipeline.c: pipelined = the reference's three concurrent stages
+    (framefilt mog | framefilt col + posidet up to the morphology | findContours), else stage after stage; also the
+    milliseconds per frame every stage was busy."""
+    import oracle_lib as O
+    orc = oracle_mog(wl)
+    p = oracle_params(wl)
+    L = len(frames_seq)
+    O.pipeline_run(orc, frames_seq, 0, 2, ALPHA, p, t_front, t_mid, pipelined, keep=False)      # frame 1 (model init) + one more, untimed
+    el, busy, _ = O.pipeline_run(orc, frames_seq, 2 % L, 4, ALPHA, p, t_front, t_mid, pipelined, keep=False)   # calibration
+    n = int(max(4, min(max_frames, budget_s / max(el / 4, 1e-6))))
+    el, busy, _ = O.pipeline_run(orc, frames_seq, 6 % L, n, ALPHA, p, t_front, t_mid, pipelined, keep=False)
+    return n / el, n, el, dict(mog=busy[0] / n * 1e3, col_inrange_morph=busy[1] / n * 1e3, contours=busy[2] / n * 1e3)
+
+
 def cpu_baseline_one(wl, frames_seq, budget_s):
-    """The oracle timed on this host, bounded sample: on all physical cores, on every hardware thread, on 32 threads
-    (round 2's figure) and on one thread; `value` is the best of them."""
+    """The oracle timed on this host, bounded sample.  Stage after stage per frame (rounds 1-3's `value`): on 32 threads,
+    on all physical cores, on every hardware thread, and on one thread.  And with the reference's STAGE PIPELINING
+    (r04; FrameFilter.cpp:59-98, PositionDetector.cpp:58-99: three component processes work on consecutive frames at the
+    same time, throughput 1 / max(stage) instead of 1 / sum(stage)): a few splits of the row workers between the MOG2
+    stage and the colour / inRange / morphology stage, contour following on a thread of its own.  `value` is the best of
+    everything -- the CPU's real best on this host."""
     phys, hw = physical_cores(), os.cpu_count() or 1
     legs = {}
     for nt in sorted({min(32, hw), phys, hw}):
-        fps, n, el = cpu_time_chain(wl, frames_seq, nt, budget_s / 3.5, 2000)
+        fps, n, el = cpu_time_chain(wl, frames_seq, nt, budget_s / 8, 2000)
         legs[nt] = dict(value=fps, frames=n, seconds=el)
-    f1, n1, el1 = cpu_time_chain(wl, frames_seq, 1, budget_s / 6, 500)
+    f1, n1, el1 = cpu_time_chain(wl, frames_seq, 1, budget_s / 8, 500)
     best = max(legs, key=lambda k: legs[k]["value"])
-    return dict(value=legs[best]["value"], unit="frames/s", cores=best, kind="port",
-                sample=f"{legs[best]['frames']} frames of one {wl['cols']}x{wl['rows']} stream, {legs[best]['seconds']:.1f} s, oracle chain "
-                       f"(MOG2, HSV, inRange, morphology: rows over a persistent pool of {best} workers; contour following 1 "
-                       f"thread, as OpenCV's findContours)",
+    # per-stage milliseconds of the best sequential leg, and the pipelined legs
+    _, _, _, seq_stage = cpu_time_pipeline(wl, frames_seq, best, best, False, budget_s / 12, 300)
+    pipe = {}
+    half = max(1, best // 2)
+    for tf, tm in sorted({(half, half), (best, half), (best, best), (max(1, min(2 * best, hw // 2)), best)}):
+        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 8, 2000)
+        pipe[f"{tf}+{tm}+1"] = dict(value=fps, frames=n, seconds=el, stage_ms=st)
+    pbest = max(pipe, key=lambda k: pipe[k]["value"])
+    v_seq, v_pipe = legs[best]["value"], pipe[pbest]["value"]
+    return dict(value=max(v_seq, v_pipe), unit="frames/s", cores=(best if v_seq >= v_pipe else sum(int(x) for x in pbest.split("+"))),
+                kind="port", method="stage-pipelined" if v_pipe > v_seq else "stage after stage",
+                value_sequential=v_seq, value_pipelined=v_pipe,
+                sample=f"{legs[best]['frames']} frames of one {wl['cols']}x{wl['rows']} stream, {legs[best]['seconds']:.1f} s, oracle chain stage "
+                       f"after stage (MOG2, HSV, inRange, morphology: rows over a persistent pool of {best} workers; contour following 1 "
+                       f"thread, as OpenCV's findContours); and {pipe[pbest]['frames']} frames, {pipe[pbest]['seconds']:.1f} s, with the "
+                       f"reference's three stages concurrent on consecutive frames (threads mog+col/morph+contours = {pbest})",
                 by_threads={str(k): v["value"] for k, v in legs.items()},
+                stage_ms_sequential=seq_stage,
+                pipelined={k: dict(value=v["value"], stage_ms=v["stage_ms"]) for k, v in pipe.items()},
+                pipelined_best=pbest,
                 value_1thread=f1, sample_1thread=f"{n1} frames, {el1:.1f} s, 1 thread")
 
 
 def cpu_baseline(name, frames_seq):
     """Benched workload (about 14 s) plus short samples of the other two sizes BASELINE.md section 2 asks for."""
-    out = cpu_baseline_one(WORKLOADS[name], frames_seq, 14.0)
+    out = cpu_baseline_one(WORKLOADS[name], frames_seq, 18.0)
     out["host"] = dict(nproc=os.cpu_count(), physical_cores=physical_cores(), cpu_model=cpu_model_string(),
                        note="`cores` = row workers of the best leg; by_threads lists every leg (32 = round 2's cap, "
                             "physical cores, all hardware threads)")
@@ -238,9 +277,11 @@ def cpu_baseline(name, frames_seq):
             continue
         st = SyntheticStream(w["rows"], w["cols"], 0, n_discs=2)
         fr = [st.frame(t, with_discs=t > 0) for t in range(4)]
-        r = cpu_baseline_one(w, fr, 5.0)
-        others[other] = dict(value=r["value"], value_1thread=r["value_1thread"], unit="frames/s", cores=r["cores"],
-                             by_threads=r["by_threads"], sample=r["sample"])
+        r = cpu_baseline_one(w, fr, 6.0)
+        others[other] = dict(value=r["value"], value_sequential=r["value_sequential"], value_pipelined=r["value_pipelined"],
+                             value_1thread=r["value_1thread"], unit="frames/s", cores=r["cores"], method=r["method"],
+                             by_threads=r["by_threads"], pipelined=r["pipelined"], stage_ms_sequential=r["stage_ms_sequential"],
+                             sample=r["sample"])
     out["other_sizes"] = others
     return out
 
@@ -487,6 +528,8 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     else:
         blocks = [elapsed]
     region = [elapsed]
+    local_steady = sorted(blocks[1:]) if len(blocks) > 1 else list(blocks)
+    local_block = local_steady[len(local_steady) // 2]
     if reduce_max:
         blocks = reduce_max(blocks)
         region = reduce_max(region)
@@ -506,7 +549,7 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     G = min(K, 256)              # the gate replays at most this many timed steps
     positions = [[Position2D.from_c(out[t * ns + s]) for s in range(ns)] for t in range(G)]
     found = sum(1 for t in range(n) for s_ in range(ns) if out[t * ns + s_].valid == 1)
-    return dict(block_s=median, blocks=blocks, n_blocks=R, region_s=region[0], steps_timed=n, isolated_block_s=iso,
+    return dict(block_s=median, local_block_s=local_block, blocks=blocks, n_blocks=R, region_s=region[0], steps_timed=n, isolated_block_s=iso,
                 positions=positions, found=found, prof=prof, models=models, handover=handover, aged=aged,
                 gate_offset=W + cal, step_s_calibration=t_cal)
 
@@ -818,7 +861,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-dense-leg", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (1080p16, 1080p1)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (1080p16, 1080p8, 1080p1, vga1)")
     ap.add_argument("--no-spin-up", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the drop-in process pipeline block (BASELINE.md section 1 methodology)")
     ap.add_argument("--quick", action="store_true", help="= --no-pmc --no-extra --no-cpu-baseline --no-pipeline (kernel A/B runs)")
@@ -897,7 +940,16 @@ def main():
     def local_barrier(l):
         return lambda: (l.hp.synchronize(), torch.cuda.synchronize())
 
-    want_gate = rank == 0 and not args.no_parity and not args.dense_model and args.input == "device"
+    # Both parity gates run on EVERY rank for every stream it owns (r04): a rank whose shard differs from the oracle
+    # must not hide behind rank 0's "ok"; the verdicts are gathered below and the line carries the worst of them.
+    want_gate = not args.no_parity and not args.dense_model and args.input == "device"
+    global THREAD_SHARE
+    THREAD_SHARE = world
+    # stream s lives on rank s // ceil(S / N) for life (oat_amd.dist.stream_partition); with the weak-scaling
+    # workloads every rank owns `ns` streams, rank r the global streams r*ns .. r*ns + ns - 1
+    from oat_amd.dist import stream_partition
+    mine = stream_partition(ns * world, world, rank)
+    assert len(mine) == ns and mine.start == rank * ns, (list(mine), rank, ns, world)
     tr = timed_run(leg, K, W, barrier, prof_every=8 if K >= 64 else 1, age_frames=AGE, export=want_gate,
                    spin=0.0 if args.no_spin_up else 0.35, spin_args=(args.workload, local_rank, rank),
                    reduce_max=reduce_max, isolated=True)
@@ -925,6 +977,19 @@ def main():
     else:
         n_found = n_found_local
 
+    per_rank = None
+    if world > 1:
+        # N > 1: every rank gates its own shard now (nothing else is timed in this process afterwards), then the
+        # verdicts, the partition and the per-rank counts travel to rank 0
+        my_par, my_detail = "skipped", None
+        if want_gate:
+            my_par, my_detail = gates(leg, tr["gate_offset"], K, positions, args.check_steps, models, handover)
+        mine_rec = dict(rank=rank, device=local_rank, streams=[mine.start, mine.stop], parity=my_par,
+                        positions_found=n_found_local, block_ms=tr["block_s"] * 1e3,
+                        k_mog_fused_ms=k1_ms(prof)[0], ms_per_step_local=tr["local_block_s"] / K * 1e3)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
+
     if rank != 0:
         if world > 1:
             dist.barrier()              # rank 0 prints before everybody leaves
@@ -934,7 +999,8 @@ def main():
     # ---- the other BASELINE configs: device timing now, their gates later ----
     extra_runs = []
     if solo and not args.no_extra and args.input == "device" and not args.dense_model:
-        for name, kk, ww in (("1080p16", 100, 40), ("1080p1", 500, 100)):
+        # (configs[2], configs[3]'s per-GPU shard, configs[1], configs[0]'s shape)
+        for name, kk, ww in (("1080p16", 100, 40), ("1080p8", 150, 40), ("1080p1", 500, 100), ("vga1", 1000, 100)):
             if name == args.workload:
                 continue
             try:
@@ -1080,7 +1146,13 @@ def main():
 
     # ---- parity gates of everything timed above (CPU), then the legs can go ----
     parity, parity_detail = "skipped", None
-    if want_gate:
+    if want_gate and world > 1:
+        bad = [r for r in per_rank if r["parity"] != "ok"]
+        parity = "ok" if not bad else f"rank {bad[0]['rank']}: {bad[0]['parity']}"
+        parity_detail = (f"both gates on every one of the {world} ranks, every stream of its shard (fresh-context masks + "
+                         f"centroids on 4 frames; first {min(args.check_steps, K)} timed steps vs the oracle continuing from "
+                         f"the device's exported model): " + ", ".join(f"rank {r['rank']} {r['parity']}" for r in per_rank))
+    elif want_gate:
         parity, parity_detail = gates(leg, tr["gate_offset"], K, positions, args.check_steps, models, handover)
     models = None
     leg.close()
@@ -1232,6 +1304,10 @@ def main():
                    "frames_per_launch": fpl,
                    "parallelism": f"streams sharded, {world} rank(s)"},
         "fps_per_gpu": fps / world,
+        "partition": {"rule": "stream s -> rank s // ceil(S / N), contiguous blocks, for life (SURVEY 8e; oat_amd.dist.stream_partition)",
+                      "streams_total": total_streams,
+                      "per_rank": per_rank if per_rank else [dict(rank=0, device=local_rank, streams=[0, ns], parity=None,
+                                                                  positions_found=n_found_local)]},
         "timing": {
             "method": f"{tr['n_blocks']} back-to-back blocks of exactly --steps {K} steps in ONE pipelined run between two "
                       "barriers (+ device synchronisation), sized so that the region lasts >= "

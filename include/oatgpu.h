@@ -12,6 +12,11 @@
  * Conventions
  *   - return 0 on success, a negative OATGPU_E_* code on failure;
  *     oatgpu_last_error() gives the text.
+ *   - a pipelined call (oatgpu_track_enqueue*, _sequence_dev, _batch*) whose kernel launches fail half-way is FATAL
+ *     for its context: the frame counts, learning-rate schedule and possibly the model have moved ahead of the
+ *     results, so every later pipelined call returns OATGPU_E_HIP ("context unusable ...") instead of silently
+ *     losing parity with the reference; results already outstanding can be collected, then destroy the context
+ *     (the reference's component would have thrown out of process() and exited, framefilter/main.cpp:278-295).
  *   - the caller owns every host buffer; the context owns all device state
  *     (MOG2 model planes, bit masks, label tables, result ring).
  *   - one context per host thread (not re-entrant).  The HIP streams the work is
@@ -33,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 6     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged */
+#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, a failed pipelined launch is fatal for its context */
 
 enum {
     OATGPU_OK = 0,
@@ -306,6 +311,10 @@ int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
  * OATGPU_E_RING_FULL from the first oatgpu_track_stage of a set when ring_depth sets are outstanding. */
 int oatgpu_track_stage(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *frame_host);
 int oatgpu_track_enqueue_staged(oatgpu_ctx *ctx, double learning_rate);
+/* Gives up a partly staged frame set: a camera ended in the middle of a round (its SINK went END, lib/shmemdf/Source.h:187-215)
+ * or a call failed after the first oatgpu_track_stage.  Waits for the copies already started (their SOURCEs may be posted
+ * afterwards), registers nothing, owes no result; the next oatgpu_track_stage starts a new set.  No-op without one. */
+int oatgpu_track_stage_abort(oatgpu_ctx *ctx);
 
 /* oatgpu_track_input_consumed blocks until every frame handed over so far has been read out of the caller's
  * buffers -- host frames (oatgpu_track_enqueue): their H2D copies are done; device frames

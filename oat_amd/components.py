@@ -363,6 +363,11 @@ class HotPath(_Context):
         self._held.append(self._staged_keep)
         self._staged_keep = []
 
+    def stage_abort(self):
+        """oatgpu_track_stage_abort: give up a partly staged set (copies already started are waited for)."""
+        self._chk(self.lib.oatgpu_track_stage_abort(self.ctx))
+        self._staged_keep = []
+
     def input_consumed_stream(self, stream):
         """The frame of ONE camera stream of the latest enqueue() has left the caller's buffer
         (oatgpu_track_input_consumed_stream; call for the streams in ascending order)."""

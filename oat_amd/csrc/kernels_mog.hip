@@ -29,6 +29,9 @@
 //     out only for planes whose bits changed.  The state in HBM stays bit-identical to
 //     updating all of it (state-parity tests).
 #include "oatgpu_internal.h"
+#ifdef OATGPU_MEASURE
+#include <stdlib.h>
+#endif
 
 namespace oatgpu {
 
@@ -413,6 +416,20 @@ struct Audit {
 #ifndef OATGPU_F2_WAVES
 #define OATGPU_F2_WAVES 8
 #endif
+// ... and the one-frame instantiations (r04): streaming loads (dense models) / default policy (everyday models)
+#ifndef OATGPU_NT1_WAVES
+#define OATGPU_NT1_WAVES 8
+#endif
+#ifndef OATGPU_F1_WAVES
+#define OATGPU_F1_WAVES 8
+#endif
+template <int CH, bool AUDIT, bool NTLD, int NF>
+constexpr int k1_waves()
+{
+    return AUDIT ? OATGPU_AUDIT_WAVES
+         : NF == 2 ? ((NTLD || CH == 1) ? OATGPU_NT2_WAVES : OATGPU_F2_WAVES)
+         : NTLD ? OATGPU_NT1_WAVES : OATGPU_F1_WAVES;
+}
 // Late arguments (r03).  The kernel's by-value arguments sit in scalar registers from the first instruction on, and at 8
 // waves per SIMD a wave has 80 of them (800 per SIMD / 8, less the trap handler's 16): the two-frame BGR instantiation
 // spilled 31 scalars to lanes of a vector register -- 61 v_writelane / v_readlane on a kernel bound by its vector
@@ -440,7 +457,7 @@ __device__ __forceinline__ RangeParams karg_rp(KArgs ka)
 }
 
 template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
-__global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD || CH == 1)) ? OATGPU_NT2_WAVES : NF == 2 ? OATGPU_F2_WAVES : 8) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+__global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
     static_assert(!FROZEN || (!AUDIT && !NTLD), "the frozen-model instantiations exist for the default-policy product kernels only");
     constexpr int kFrozenMode = AUDIT ? 2 : FROZEN ? 1 : 0;
@@ -452,7 +469,11 @@ __global__ __launch_bounds__(256, AUDIT ? OATGPU_AUDIT_WAVES : (NF == 2 && (NTLD
     Audit<AUDIT> au;
     // (late arguments: the product two-frame BGR instantiation only -- the others are not bound by their instruction count
     // or were left as compiled)
+#ifdef OATGPU_LATE_NTLD              // (make variant DEFS=-DOATGPU_LATE_NTLD: the A/B build)
+    constexpr bool kLate = !AUDIT && CH == 3;
+#else
     constexpr bool kLate = !NTLD && !AUDIT && CH == 3;
+#endif
     KArgs ka = (KArgs)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + kMogLaunchArgOffset);
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
     // 79 % VALU-busy at 370 VALU instructions per wave before, profiles/r02_k1_sq_counters_before.md): every plane
@@ -917,7 +938,13 @@ template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
 static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
 {
     const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
-    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), 0, st, g, a, first_stream);
+    unsigned lds = 0;
+#ifdef OATGPU_MEASURE                // (A/B builds only) OATGPU_K1_LDS=bytes: unused dynamic LDS per workgroup, which holds the
+                                     // occupancy down -- 21 000 B = 7 workgroups a CU = 7 waves a SIMD, 26 000 = 6, 32 000 = 5
+    static const unsigned env_lds = getenv("OATGPU_K1_LDS") ? (unsigned)atoi(getenv("OATGPU_K1_LDS")) : 0u;
+    lds = env_lds;
+#endif
+    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, g, a, first_stream);
 }
 
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)

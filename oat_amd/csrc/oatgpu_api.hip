@@ -91,6 +91,8 @@ struct oatgpu_ctx {
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
     int last_q = 0;
     std::string err;
+    bool broken = false;             // a launch of the pipelined path failed half-way: the model and its rate schedule are ahead
+                                     // of the results -- every later pipelined call is refused (oatgpu.h "Errors")
     // Temporal fusion (kernels_mog.hip "Two frames a launch"): with fuse == 2 a pipelined enqueue only REGISTERS its
     // frame (ring slot, counters); the kernels go out when the next frame is enqueued -- K1 once for both -- or when
     // somebody needs the frame's result or the model (collect / ready of that very frame, every synchronous entry
@@ -1112,6 +1114,7 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
     const int n = c->cfg.n_streams;
     if (stream_ix < 0 || stream_ix >= n) return fail(c, OATGPU_E_INVALID, "stream index %d out of range", stream_ix);
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
     if (c->staged_count == 0) {
         if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
         { const int rc = ensure_host_ring(c); if (rc) return rc; }
@@ -1123,8 +1126,10 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
     const size_t fb = (size_t)c->g.H * c->g.W * c->cfg.channels;
     uint8_t *dst = c->frames_ring + (size_t)c->stage_slot * fb * n;
     if (!c->stream_c2 && n > 1 && !c->private_streams) {
-        c->stream_c2 = acquire_copy_stream2(c->cfg.device);
-        if (c->stream_c2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming | hipEventDisableSystemFence));
+        hipStream_t s2 = acquire_copy_stream2(c->cfg.device);
+        // (the event first: a context that shows a second copy stream always has the event enqueue_staged records on it)
+        if (s2 && !c->ev_c2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming | hipEventDisableSystemFence));
+        c->stream_c2 = s2;
     }
     hipStream_t cs = (c->stream_c2 && (c->staged_count & 1)) ? c->stream_c2 : c->stream_c;
     HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, cs));
@@ -1153,6 +1158,27 @@ extern "C" int oatgpu_track_enqueue_staged(oatgpu_ctx *c, double lr)
     c->staged_count = 0;
     const int rc = enqueue_frames(c, c->frames_ring + (size_t)slot * sb, lr, c->copy_ev[slot]);
     return rc;
+}
+
+// A partly staged frame set is given up (a camera ended in the middle of a round, an error after the first
+// oatgpu_track_stage): the copies already on their way are waited for -- they write into the staging slot, which the
+// next set will reuse -- and the set is forgotten; nothing was registered, no result is owed for it.
+extern "C" int oatgpu_track_stage_abort(oatgpu_ctx *c)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (c->staged_count == 0) return OATGPU_OK;
+    const int n = c->cfg.n_streams;
+    hipError_t worst = hipSetDevice(c->cfg.device);
+    for (int s = 0; s < n && c->stage_slot >= 0; ++s)
+        if (c->staged[(size_t)s]) {
+            const hipError_t e = hipEventSynchronize(c->copy_ev_s[(size_t)c->stage_slot * n + s]);
+            if (e != hipSuccess) worst = e;
+        }
+    c->staged.assign((size_t)n, 0);
+    c->staged_count = 0;
+    c->stage_slot = -1;
+    if (worst != hipSuccess) return fail(c, OATGPU_E_HIP, "oatgpu_track_stage_abort: %s", hipGetErrorString(worst));
+    return OATGPU_OK;
 }
 
 extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_host, int32_t n, double lr)
@@ -1332,6 +1358,7 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     if (!c || !frames_dev) return fail(c, OATGPU_E_INVALID, "null argument");
     // (a set being staged owns the next ring slot: nothing else may be enqueued until oatgpu_track_enqueue_staged took it)
     if (c->staged_count) return fail(c, OATGPU_E_INVALID, "a frame set is being staged (oatgpu_track_stage): finish it with oatgpu_track_enqueue_staged");
+    if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     oatgpu_ctx::FrameJob cur;
@@ -1349,7 +1376,6 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
             c->enq_total--;
             c->ring_count--;
             c->err += " (the frame registered by the previous enqueue was dropped with this one)";
-            return rc;
         }
     } else if (may_fuse) {
         c->pend = cur;
@@ -1357,7 +1383,13 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     } else {
         rc = launch_jobs(c, &cur, 1);
     }
-    if (rc) return rc;
+    if (rc) {
+        // launch_jobs had advanced the streams' frame counts and rate schedules (mog_begin) and may have updated the
+        // model before it failed: results from here on would silently differ from the reference's.  Fatal for the
+        // context (sticky): results already outstanding can still be collected, nothing new is accepted.
+        c->broken = true;
+        return rc;
+    }
     c->enq_total++;
     c->ring_count++;
     return OATGPU_OK;

@@ -53,7 +53,7 @@ class Traffic(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 6          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 7          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -105,6 +105,7 @@ SIGNATURES = {
     "oatgpu_track_input_consumed_stream": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_track_stage": (C.c_int, [_ctx, C.c_int32, _u8p]),
     "oatgpu_track_enqueue_staged": (C.c_int, [_ctx, C.c_double]),
+    "oatgpu_track_stage_abort": (C.c_int, [_ctx]),
     "oatgpu_track_ready": (C.c_int, [_ctx]),
     "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),
     "oatgpu_mog_get_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.POINTER(C.c_int32)]),

@@ -118,6 +118,24 @@ protected:
     // PositionDetector.cpp:40-56, for every stream
     bool connectToNode() override
     {
+        // A tracker that fails while connecting (a camera with another geometry, no device memory, an unreadable mask
+        // or model file) still BINDS its SINKs on the way out, so that its destructor sets them END (Sink.h:73-91) and
+        // the consumers of this shard's cameras end instead of waiting for a sink that will never appear -- with
+        // several shards in one process the others keep running, where the reference's one-camera process would
+        // simply have exited (framefilter/main.cpp:278-295).
+        try {
+            return connect_all();
+        } catch (...) {
+            for (int s = 0; s < n_; ++s) {
+                if ((size_t)s < shared_positions_.size()) continue;        // bound before the failure
+                try { position_sinks_[s].bind(sink_addresses_[s], sink_addresses_[s]); } catch (...) {}
+            }
+            throw;
+        }
+    }
+
+    bool connect_all()
+    {
         for (int s = 0; s < n_; ++s) frame_sources_[s].touch(source_addresses_[s]);
         FrameParams p0{};
         for (int s = 0; s < n_; ++s) {
@@ -191,6 +209,7 @@ protected:
                     gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, q));
                     frame_sources_[q].post();
                 }
+                gpu_.check(oatgpu_track_stage_abort(gpu_.ctx));        // the partly staged set is given up, nothing is owed for it
                 while (!pending_.empty() && !quit) publish();
                 return 1;
             }
@@ -300,12 +319,17 @@ int main(int argc, char **argv)
         if (shards.size() == 1) return shards[0]->run();
         // one thread per shard: a device context belongs to the thread that drives it; SIGINT reaches every loop
         // through `quit` (the waits are 10 ms slices), END of a shard's SOURCEs ends that shard only
+        // A shard that ends -- END of its SOURCEs, or a failure -- is DESTROYED at once, by its own thread: its SINKs go
+        // END and its SOURCE slots are released while the other shards keep running, exactly what the exit of the
+        // reference's one-camera process does for its consumers and producers (lib/shmemdf/Sink.h:73-91,
+        // Source.h:90-112); the process exit code still reports the failure.
         std::vector<int> rc(shards.size(), 0);
         std::vector<std::thread> th;
         for (size_t k = 0; k < shards.size(); ++k)
             th.emplace_back([&, k] {
                 pin_thread_to_device_node(shards[k]->cfg_.device);      // the shard's thread next to its GPU
                 rc[k] = shards[k]->run();
+                shards[k].reset();
             });
         for (auto &t : th) t.join();
         for (int r : rc) if (r) return r;

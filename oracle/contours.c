@@ -515,6 +515,22 @@ void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double lear
     oat_chain_step_from(m, NULL, frame, rows, cols, learning_rate, p, scratch, thr_out, out, nthreads);
 }
 
+/* The three stages of the chain as Oat runs them -- three component processes (pipeline.c runs them concurrently):
+ *   front  = framefilt mog                         oat_mog2_filter_from (mog2.c)
+ *   middle = framefilt col -C HSV + posidet hsv up to the morphology (or the GREY window of posidet thresh)
+ *   back   = siftContours                          oat_sift_contours
+ * middle: work = the filtered frame (rows*cols*channels), hsv = rows*cols*3 scratch, thr = rows*cols out,
+ * tmp = rows*cols morphology temporary. */
+void oat_chain_middle(const uint8_t *work, int channels, int rows, int cols, const oat_hsv_params *p, uint8_t *hsv,
+                      uint8_t *thr, uint8_t *tmp, int nthreads)
+{
+    int lo[3] = { p->h_lo, p->s_lo, p->v_lo }, hi[3] = { p->h_hi, p->s_hi, p->v_hi };
+    chain_job j = { 0, (uint8_t *)work, thr, hsv, rows, cols, channels, 0, 0, 0, lo, hi };   /* k carries the channel count for stage 0 */
+    chain_parallel(j, nthreads);
+    if (p->erode > 0) morph_mt(thr, tmp, rows, cols, p->erode, 1, nthreads);
+    if (p->dilate > 0) morph_mt(thr, tmp, rows, cols, p->dilate, 0, nthreads);
+}
+
 /* src != NULL: the caller's frame stays untouched; `work` (rows*cols*channels bytes) receives the filtered copy */
 void oat_chain_step_from(oat_mog2 *m, const uint8_t *src, uint8_t *work, int rows, int cols, double learning_rate,
                          const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
@@ -525,11 +541,7 @@ void oat_chain_step_from(oat_mog2 *m, const uint8_t *src, uint8_t *work, int row
     uint8_t *hsv = scratch + n;         /* 3n  */
     uint8_t *thr = scratch + 4 * n;     /* n   */
     oat_mog2_filter_from(m, src, work, mask, learning_rate, nthreads);
-    int lo[3] = { p->h_lo, p->s_lo, p->v_lo }, hi[3] = { p->h_hi, p->s_hi, p->v_hi };
-    chain_job j = { 0, work, thr, hsv, rows, cols, oat_mog2_channels(m), 0, 0, 0, lo, hi };   /* k carries the channel count for stage 0 */
-    chain_parallel(j, nthreads);
-    if (p->erode > 0) morph_mt(thr, mask, rows, cols, p->erode, 1, nthreads);
-    if (p->dilate > 0) morph_mt(thr, mask, rows, cols, p->dilate, 0, nthreads);
+    oat_chain_middle(work, oat_mog2_channels(m), rows, cols, p, hsv, thr, mask, nthreads);
     if (thr_out) memcpy(thr_out, thr, n);
     oat_sift_contours(thr, rows, cols, p->min_area, p->max_area, out);
 }

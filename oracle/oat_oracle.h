@@ -72,7 +72,11 @@ void oat_mog2_filter(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning
 void oat_mog2_filter_mt(oat_mog2 *m, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
 void oat_mog2_filter_from(oat_mog2 *m, const uint8_t *src, uint8_t *frame, uint8_t *mask, double learning_rate, int nthreads);
 
-/* pool.c: persistent workers for the row-parallel stages (created on first use, woken per stage) */
+/* pool.c: persistent workers for the row-parallel stages (created on first use, woken per stage).  oat_pool_run uses the
+ * calling thread's current pool (oat_pool_make_current; NULL = the process-wide default pool). */
+typedef struct oat_pool oat_pool;
+oat_pool *oat_pool_create(void);
+void oat_pool_make_current(oat_pool *p);
 void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs);
 int oat_pool_max(void);
 
@@ -222,6 +226,22 @@ void oat_chain_step(oat_mog2 *m, uint8_t *frame, int rows, int cols, double lear
 void oat_chain_step_from(oat_mog2 *m, const uint8_t *src, uint8_t *work, int rows, int cols, double learning_rate,
                          const oat_hsv_params *p, uint8_t *scratch, uint8_t *thr_out,
                          oat_detection *out, int nthreads);
+
+/* stage 2 of 3 of the chain (framefilt col + posidet up to the morphology), see contours.c */
+void oat_chain_middle(const uint8_t *work, int channels, int rows, int cols, const oat_hsv_params *p, uint8_t *hsv,
+                      uint8_t *thr, uint8_t *tmp, int nthreads);
+
+/* pipeline.c -- the chain over a sequence of frames with the reference's STAGE PIPELINING: Oat runs framefilt mog,
+ * framefilt col and posidet hsv as three concurrent processes (FrameFilter.cpp:59-98, PositionDetector.cpp:58-99,
+ * README.md:1708-1714), so its throughput is 1 / max(stage), not 1 / sum(stage).  n frames, frame i = frames[(first + i)
+ * % nfile] (read-only), detections to out[i] (may be NULL).  pipelined = 0: the stages one after the other per frame on
+ * the calling thread with t_front row workers (what oat_chain_step does); 1: three stage threads -- mog with t_front row
+ * workers, col + inRange + morphology with t_mid, contour following alone -- two frame buffers between neighbours (a
+ * sink's one shared slot plus the consumer's own copy).  stage_s[3] receives the seconds each stage was busy.  Returns
+ * the wall-clock seconds of the n frames.  Results are those of n oat_chain_step calls. */
+double oat_pipeline_run(oat_mog2 *m, const uint8_t *const *frames, int nfile, int first, int n, int rows, int cols,
+                        double learning_rate, const oat_hsv_params *p, int t_front, int t_mid, int pipelined,
+                        oat_detection *out, double stage_s[3]);
 
 /* ------------------------------------------------- posifilt kalman -------- */
 

@@ -1,4 +1,4 @@
-/* pool.c -- a persistent worker pool for the row-parallel stages of the CPU baseline (TEST INFRASTRUCTURE, like the
+/* pool.c -- persistent worker pools for the row-parallel stages of the CPU baseline (TEST INFRASTRUCTURE, like the
  * rest of oracle/: only tests/, __graft_entry__.smoke() and bench.py's parity gates / cpu_baseline leg load it).
  *
  * OpenCV runs MOG2, cvtColor, inRange and the morphology through parallel_for_, whose threads live as long as the
@@ -7,7 +7,12 @@
  * threads.  Here the workers are created once; a stage wakes exactly the workers it has jobs
  * for, each through a semaphore of its own (one condition variable for all of them was a thundering herd: every
  * worker ever created woke for every stage), runs job 0 on the calling thread and waits for a completion count.
- * Results do not depend on the number of workers. */
+ * Results do not depend on the number of workers.
+ *
+ * r04: a pool is an OBJECT.  oat_pool_run() uses the calling thread's current pool (oat_pool_make_current), the
+ * process-wide default one otherwise -- so the stage threads of pipeline.c, which stand for Oat's concurrent
+ * component processes (framefilt mog | framefilt col + posidet front | findContours), each drive row workers of
+ * their own at the same time, as three OpenCV processes would. */
 #define _GNU_SOURCE
 #include "oat_oracle.h"
 
@@ -21,28 +26,52 @@
 
 #define OAT_POOL_MAX 512
 
-static pthread_mutex_t run_mu = PTHREAD_MUTEX_INITIALIZER;     /* one oat_pool_run at a time */
-static sem_t wake[OAT_POOL_MAX];                               /* worker i sleeps on wake[i] */
-static sem_t done;
-static int n_workers = 0;                                      /* workers 1 .. n_workers exist (0 is the caller) */
-static int done_ready = 0;
-static atomic_int remaining;
-static void *(*cur_fn)(void *);
-static char *cur_jobs;
-static size_t cur_stride;
+struct oat_pool {
+    pthread_mutex_t run_mu;                  /* one oat_pool_run at a time per pool */
+    sem_t wake[OAT_POOL_MAX];                /* worker i sleeps on wake[i] */
+    sem_t done;
+    int n_workers;                           /* workers 1 .. n_workers exist (0 is the caller) */
+    atomic_int remaining;
+    void *(*cur_fn)(void *);
+    char *cur_jobs;
+    size_t cur_stride;
+};
+
+typedef struct { struct oat_pool *pool; int id; } worker_arg;
+
+static struct oat_pool default_pool = { .run_mu = PTHREAD_MUTEX_INITIALIZER };
+static pthread_once_t default_once = PTHREAD_ONCE_INIT;
+static void default_init(void) { sem_init(&default_pool.done, 0, 0); }
+static __thread struct oat_pool *current_pool = NULL;
 
 static void *pool_worker(void *arg)
 {
-    const int id = (int)(intptr_t)arg;
+    worker_arg *wa = (worker_arg *)arg;
+    struct oat_pool *p = wa->pool;
+    const int id = wa->id;
+    free(wa);
     for (;;) {
-        while (sem_wait(&wake[id]) != 0) {}
-        cur_fn(cur_jobs + (size_t)id * cur_stride);            /* (published before the sem_post that woke us) */
-        if (atomic_fetch_sub(&remaining, 1) == 1) sem_post(&done);
+        while (sem_wait(&p->wake[id]) != 0) {}
+        p->cur_fn(p->cur_jobs + (size_t)id * p->cur_stride);   /* (published before the sem_post that woke us) */
+        if (atomic_fetch_sub(&p->remaining, 1) == 1) sem_post(&p->done);
     }
     return NULL;
 }
 
 int oat_pool_max(void) { return OAT_POOL_MAX; }
+
+oat_pool *oat_pool_create(void)
+{
+    struct oat_pool *p = calloc(1, sizeof *p);
+    if (!p) return NULL;
+    pthread_mutex_init(&p->run_mu, NULL);
+    sem_init(&p->done, 0, 0);
+    return p;
+}
+
+/* the calling thread's oat_pool_run()s (and so every row-parallel oracle stage it calls) use `p` from now on; NULL =
+ * the process-wide default pool.  Pools are never destroyed (their workers are detached and sleep). */
+void oat_pool_make_current(oat_pool *p) { current_pool = p; }
 
 /* fn(jobs + i * stride) for i in [0, njobs), in parallel (job 0 on the calling thread); returns when all are done */
 void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs)
@@ -50,13 +79,17 @@ void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs)
     if (njobs <= 0) return;
     if (njobs == 1) { fn(jobs); return; }
     if (njobs > OAT_POOL_MAX) njobs = OAT_POOL_MAX;            /* (callers cap their job arrays at 512 too) */
-    pthread_mutex_lock(&run_mu);
-    if (!done_ready) { sem_init(&done, 0, 0); done_ready = 1; }
-    while (n_workers < njobs - 1) {                            /* grow on demand; workers are never retired */
-        const int id = n_workers + 1;
+    struct oat_pool *p = current_pool;
+    if (!p) { pthread_once(&default_once, default_init); p = &default_pool; }
+    pthread_mutex_lock(&p->run_mu);
+    while (p->n_workers < njobs - 1) {                         /* grow on demand; workers are never retired */
+        const int id = p->n_workers + 1;
         pthread_attr_t at;
         pthread_t th;
-        sem_init(&wake[id], 0, 0);
+        worker_arg *wa = malloc(sizeof *wa);
+        if (!wa) break;
+        wa->pool = p; wa->id = id;
+        sem_init(&p->wake[id], 0, 0);
         pthread_attr_init(&at);
         pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
         {   /* the workers may run on every CPU of the machine, whatever the creating thread is pinned to (bench.py
@@ -67,17 +100,17 @@ void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs)
             for (long c = 0; c < ncpu && c < CPU_SETSIZE; c++) CPU_SET((int)c, &all);
             pthread_attr_setaffinity_np(&at, sizeof all, &all);
         }
-        const int rc = pthread_create(&th, &at, pool_worker, (void *)(intptr_t)id);
+        const int rc = pthread_create(&th, &at, pool_worker, wa);
         pthread_attr_destroy(&at);
-        if (rc != 0) break;
-        n_workers = id;
+        if (rc != 0) { free(wa); break; }
+        p->n_workers = id;
     }
-    const int par = n_workers + 1 < njobs ? n_workers + 1 : njobs;     /* jobs that get a thread of their own */
-    cur_fn = fn; cur_jobs = (char *)jobs; cur_stride = stride;
-    atomic_store(&remaining, par - 1);
-    for (int i = 1; i < par; i++) sem_post(&wake[i]);
+    const int par = p->n_workers + 1 < njobs ? p->n_workers + 1 : njobs;     /* jobs that get a thread of their own */
+    p->cur_fn = fn; p->cur_jobs = (char *)jobs; p->cur_stride = stride;
+    atomic_store(&p->remaining, par - 1);
+    for (int i = 1; i < par; i++) sem_post(&p->wake[i]);
     fn(jobs);
     for (int i = par; i < njobs; i++) fn((char *)jobs + (size_t)i * stride);   /* (threads could not be created) */
-    if (par > 1) while (sem_wait(&done) != 0) {}
-    pthread_mutex_unlock(&run_mu);
+    if (par > 1) while (sem_wait(&p->done) != 0) {}
+    pthread_mutex_unlock(&p->run_mu);
 }

@@ -89,6 +89,10 @@ def _load():
                                         u8p, u8p, C.POINTER(Detection), C.c_int]
     lib.oat_chain_step.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_double, C.POINTER(HsvParams),
                                    u8p, u8p, C.POINTER(Detection), C.c_int]
+    lib.oat_pipeline_run.restype = C.c_double
+    lib.oat_pipeline_run.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                     C.POINTER(HsvParams), C.c_int, C.c_int, C.c_int, C.POINTER(Detection),
+                                     C.POINTER(C.c_double)]
     lib.oat_bsub_create.restype = C.c_void_p
     lib.oat_bsub_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     lib.oat_bsub_destroy.argtypes = [C.c_void_p]
@@ -274,6 +278,21 @@ def chain_step(mog, frame, lr, p, nthreads=1):
     lib.oat_chain_step_from(mog.h, _p(frame), _p(work), mog.rows, mog.cols, float(lr), C.byref(p),
                             _p(scratch), _p(thr), C.byref(d), int(nthreads))
     return d.as_dict(), thr
+
+
+def pipeline_run(mog, frames, first, n, lr, p, t_front=1, t_mid=1, pipelined=True, keep=True):
+    """oat_pipeline_run (oracle/pipeline.c): n frames, frame i = frames[(first + i) % len(frames)], through the chain
+    with the reference's stage pipelining (three concurrent stages) or, pipelined=False, stage after stage.
+    -> (wall seconds, [busy seconds of mog, col+inRange+morphology, contours], [detection dicts] or None)."""
+    fs = [_c(f) for f in frames]
+    ptrs = (_u8p * len(fs))(*[_p(f) for f in fs])
+    out = (Detection * n)() if keep else None
+    st = (C.c_double * 3)()
+    el = lib.oat_pipeline_run(mog.h, ptrs, len(fs), int(first), int(n), mog.rows, mog.cols, float(lr), C.byref(p),
+                              int(t_front), int(t_mid), 1 if pipelined else 0, out, st)
+    if el < 0:
+        raise MemoryError("oat_pipeline_run")
+    return el, [st[0], st[1], st[2]], ([d.as_dict() for d in out] if keep else None)
 
 
 def blur(img, k):

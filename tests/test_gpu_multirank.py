@@ -41,6 +41,41 @@ def test_bench_two_ranks_over_gloo_share_one_gpu():
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] is None      # N = 1-only legs are skipped, and say so
 
 
+@pytest.mark.parametrize("workload,per_rank", [("1080p8", 8), ("4k1", 1)])
+def test_bench_eight_ranks_on_one_gpu_run_configs_3_and_4(workload, per_rank):
+    """BASELINE configs[3] (64 x 1080p as 8 ranks x 8 streams) and configs[4] (8 x 4K, one per rank) in their 8-RANK form
+    on the one GPU there is: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --backend
+    gloo`.  Eight processes, eight contexts, ~13 GB / ~7 GB of models on device 0.  Asserted: SURVEY 8e's partition (rank
+    r owns global streams r*per .. r*per + per - 1), BOTH parity gates green on EVERY rank for every stream of its shard,
+    one JSON line from rank 0 whose value counts all ranks' streams, the N = 1-only legs absent.  What this cannot
+    show is scaling over xGMI: that stays unmeasured until a SCALE record exists."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    K = 20
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
+           "--workload", workload, "--steps", str(K), "--warmup", "5", "--age", "40", "--pool", "8", "--check-steps", "4",
+           "--no-spin-up"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == K and j["scaling"] == "weak" and j["config"]["name"] == workload
+    assert j["config"]["streams_per_gpu"] == per_rank
+    part = j["partition"]
+    assert part["streams_total"] == 8 * per_rank and len(part["per_rank"]) == 8
+    for rk, rec in enumerate(part["per_rank"]):
+        assert rec["rank"] == rk and rec["streams"] == [rk * per_rank, (rk + 1) * per_rank], rec
+        assert rec["parity"] == "ok", rec                      # every rank gated its own shard
+        assert rec["positions_found"] > 0, rec
+    assert j["parity"] == "ok", j["parity"]
+    timed = j["timing"]["steps_timed"]
+    assert timed % K == 0 and j["positions_expected"] == 8 * per_rank * timed
+    assert j["positions_found"] >= 0.9 * j["positions_expected"]
+    assert abs(j["value"] - 8 * per_rank * K / (j["ms_per_step"] * K / 1e3)) < 1e-6 * j["value"]
+    assert j["cpu_baseline"] is None and j["roofline"]["frac"] is None and j.get("extra_workloads") is None
+
+
 def test_rccl_single_rank_init_allreduce_teardown():
     """backend "nccl" IS RCCL on ROCm: a world of one must initialise, reduce on the GPU and tear down."""
     code = r"""

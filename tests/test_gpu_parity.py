@@ -1190,6 +1190,37 @@ def test_stage_camera_by_camera_equals_enqueue(A):
     hp.collect(); hp.collect()
 
 
+def test_stage_abort_gives_up_a_partly_staged_set(A):
+    """oatgpu_track_stage_abort (ABI 7): a camera ended in the middle of a round.  The set is forgotten --
+    no result is owed, the model has not moved -- and the context goes on: the next complete set gives what a context
+    that never saw the aborted frames gives, enqueue() is accepted again, and aborting nothing is a no-op."""
+    rows, cols, n = 90, 170, 3
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    kw = dict(n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+    hp = A.HotPath(rows, cols, ring_depth=2, **kw)
+    ref = A.HotPath(rows, cols, **kw)
+    streams = [SyntheticStream(rows, cols, 90 + s, n_discs=1, radius=9) for s in range(n)]
+    hp.stage_abort()                                                  # nothing staged: no-op
+    junk = np.full((rows, cols, 3), 200, np.uint8)
+    for t in range(8):
+        frames = [st.frame(t, with_discs=t > 0) for st in streams]
+        want = ref.track(frames)
+        if t % 3 == 1:                                               # a round that dies after one or two cameras
+            for s_ in range(1 + t % 2):
+                hp.stage(s_, junk)
+            assert hp.lib.oatgpu_track_enqueue_staged(hp.ctx, 0.01) < 0
+            hp.stage_abort()
+            assert hp.outstanding() == 0                             # nothing was registered
+        if t % 2 == 0:
+            for s_ in range(n):
+                hp.stage(s_, frames[s_])
+            hp.enqueue_staged()
+        else:
+            hp.enqueue(frames)                                       # accepted again: no set is open
+        assert hp.collect() == want, t
+    assert hp.outstanding() == 0
+
+
 def test_back_half_speculation_and_repair(A):
     """The pipelined path launches the row scan + the single-workgroup LDS blob kernel only, as long as frames are
     sparse enough for it; a frame that is not (here: thousands of foreground specks) comes back marked and

@@ -380,13 +380,14 @@ def test_batched_tracker_four_cameras_match_their_oracles(host_bins, tmp_path, r
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ncam,devices", [(4, "0,0"), (3, "0,0"), (2, "0,0,0")])
+@pytest.mark.parametrize("ncam,devices", [(4, "0,0"), (3, "0,0"), (2, "0,0,0"), (16, "0,0,0,0,0,0,0,0"), (9, "0,0,0,0,0,0,0,0")])
 def test_batched_tracker_sharded_over_device_contexts(host_bins, tmp_path, ncam, devices):
     """`oat-track-hip --gpu-index D0,D1,..`: the C++ launcher of SURVEY 8e's partition -- the SOURCE list cut into
     contiguous blocks, one batched tracker (own context, own thread) per listed device.  On a one-GPU box the same
     device is listed more than once: two or three contexts on device 0, even and uneven blocks, more devices than
     cameras.  Every camera must equal ITS oracle, token by token.  (BASELINE configs[3] / [4] are this with eight
-    devices; unmeasured on multi-GPU hardware.)"""
+    devices; unmeasured on multi-GPU hardware.)  r04: the EIGHT-shard forms on the one GPU -- 16 cameras as 8 contexts x 2,
+    and 9 cameras (uneven: ceil(9/8) = 2 per shard, five shards, the last with one camera)."""
     import oracle_lib as O
     from oat_amd.synth import SyntheticStream
     rows, cols, n = 240, 320, 16
@@ -406,6 +407,117 @@ def test_batched_tracker_sharded_over_device_contexts(host_bins, tmp_path, ncam,
                 hits += 1
                 assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
         assert hits >= n - 3, (s, hits)
+
+
+def _start_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200):
+    """Like _run_batched, but the cameras may differ in geometry and frame count and nothing is waited for: returns
+    (tracker, readers, reader files, feeders, addresses, t_feeders_started)."""
+    n = len(streams_frames)
+    tag = "oat_t_" + uuid.uuid4().hex[:8]
+    srcs = [f"{tag}raw{s}" for s in range(n)]
+    snks = [f"{tag}pos{s}" for s in range(n)]
+    B = lambda b: os.path.join(host_bins, b)
+    files = [open(tmp_path / f"reader{s}.out", "w+") for s in range(n)]
+    readers = [subprocess.Popen([B("oat-posi-cout"), a], stdout=f, stderr=subprocess.DEVNULL, text=True) for a, f in zip(snks, files)]
+    tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
+                                "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
+                                "--ring", str(ring)] + list(extra), stderr=subprocess.PIPE, text=True)
+    time.sleep(3.0)
+    feeders = []
+    t0 = time.monotonic()
+    for s in range(n):
+        rows, cols = streams_frames[s][0].shape[:2]
+        raw = tmp_path / f"frames{s}.raw"
+        np.stack(streams_frames[s]).tofile(raw)
+        feeders.append(subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", str(raw), "--rows", str(rows), "--cols",
+                                         str(cols), "-n", str(len(streams_frames[s])), "-r", str(fps)]))
+    return tracker, readers, files, feeders, srcs + snks, t0
+
+
+def _tokens(fl):
+    fl.seek(0)
+    return [json.loads(l) for l in fl.read().splitlines() if l.strip()]
+
+
+@pytest.mark.gpu
+def test_failing_shard_ends_its_sinks_at_once_and_the_others_keep_their_tokens(host_bins, tmp_path):
+    """VERDICT r03 item 5 / weak 11.  Two contexts on one GPU (`--gpu-index 0,0`, four cameras): camera 3 has another
+    geometry than camera 2, so shard 1 fails while connecting.  Its tracker is destroyed at once by its own thread --
+    its SINKs are bound on the way out and go END (lib/shmemdf/Sink.h:73-91), so the consumers of cameras 2 and 3 end
+    right away instead of blocking for as long as shard 0 runs -- shard 0's cameras get every one of their tokens, equal
+    to their oracles, and the process exit code still reports the failure (framefilter/main.cpp:278-295)."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 50
+    streams = [SyntheticStream(rows, cols, 60 + s, n_discs=1, radius=8 + 3 * s) for s in range(3)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
+    odd = SyntheticStream(120, 160, 63, n_discs=1, radius=6)
+    frames.append([odd.frame(t, with_discs=t > 0) for t in range(n)])
+    tracker, readers, files, feeders, addrs, t0 = _start_batched(host_bins, tmp_path, frames, extra=("--gpu-index", "0,0"), fps=20)
+    try:
+        # shard 1's consumers end while shard 0 (50 frames at 20 fps = 2.5 s) is still being served
+        for r in readers[2:]:
+            r.wait(timeout=2.0)
+        t_end = time.monotonic() - t0
+        assert t_end < 1.5, t_end
+        assert readers[0].poll() is None and readers[1].poll() is None and tracker.poll() is None      # shard 0 goes on
+        for r in readers[:2]:
+            r.wait(timeout=120)
+        for f in feeders:
+            f.wait(timeout=60)
+        _, err = tracker.communicate(timeout=60)
+    finally:
+        for p_ in readers + feeders + [tracker]:
+            if p_.poll() is None:
+                p_.kill()
+        subprocess.run([os.path.join(host_bins, "oat-clean-hip")] + addrs, capture_output=True)
+    assert tracker.returncode == 255 and "same frame geometry" in err, (tracker.returncode, err[-500:])
+    assert _tokens(files[2]) == [] and _tokens(files[3]) == []
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    for s in range(2):
+        got = _tokens(files[s])
+        assert len(got) == n, (s, len(got))
+        orc = O.Mog2(rows, cols, 3)
+        for t, (f, g) in enumerate(zip(frames[s], got)):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], (s, t, g)
+            if want["valid"]:
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
+
+
+@pytest.mark.gpu
+def test_end_on_one_camera_in_the_middle_of_a_round(host_bins, tmp_path):
+    """END on camera 1 of 3 (its frame server stops 5 frames early) while camera 0's frame of that round is already
+    staged: the partly staged set is given up (oatgpu_track_stage_abort), every COMPLETE round still gets its token
+    on all three SINKs -- equal to the oracles -- and the component exits 0 like the reference at END of stream
+    (framefilter/main.cpp:271-276)."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n, short = 240, 320, 20, 15
+    streams = [SyntheticStream(rows, cols, 70 + s, n_discs=1, radius=8 + 3 * s) for s in range(3)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n if s != 1 else short)] for s, st in enumerate(streams)]
+    tracker, readers, files, feeders, addrs, _ = _start_batched(host_bins, tmp_path, frames, fps=100)
+    try:
+        for r in readers:
+            r.wait(timeout=120)
+        _, err = tracker.communicate(timeout=60)
+        feeders[1].wait(timeout=60)
+    finally:
+        for p_ in readers + feeders + [tracker]:                     # (cameras 0 and 2 still hold frames nobody will take)
+            if p_.poll() is None:
+                p_.kill()
+        subprocess.run([os.path.join(host_bins, "oat-clean-hip")] + addrs, capture_output=True)
+    assert tracker.returncode == 0, err[-500:]
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    for s in range(3):
+        got = _tokens(files[s])
+        assert len(got) == short, (s, len(got))
+        orc = O.Mog2(rows, cols, 3)
+        for t, (f, g) in enumerate(zip(frames[s], got)):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], (s, t, g)
+            if want["valid"]:
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
 
 
 def _write_pnm(path, img):

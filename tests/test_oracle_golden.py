@@ -406,3 +406,39 @@ def test_homography_filter_known_answers():
     h = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1e-8]          # |w| <= FLT_EPSILON
     assert O.homography(h, True, 5.0, 7.0)[:2] == (0.0, 0.0)
     assert O.homography(h, False, 5.0, 7.0)[:2] == (5.0, 7.0)
+
+
+def test_pipelined_chain_equals_the_sequential_chain():
+    """oracle/pipeline.c (bench.py's cpu_baseline with the reference's stage pipelining: framefilt mog | framefilt col +
+    posidet front | findContours as three concurrent stages, FrameFilter.cpp:59-98 / PositionDetector.cpp:58-99): the
+    detections of a frame sequence are those of oat_chain_step frame by frame, pipelined or not, whatever the number of
+    row workers per stage, BGR and GREY; the model ends bit-identical."""
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 96, 160, 14
+    st = SyntheticStream(rows, cols, 5, n_discs=2, radius=7)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(n)]
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=5.0, max_area=1e5)
+    ref = O.Mog2(rows, cols, 3)
+    want = [O.chain_step(ref, f, 0.01, p)[0] for f in frames]
+    assert sum(w["valid"] for w in want) >= n // 2
+    for pipelined, tf, tm in ((False, 1, 1), (False, 3, 3), (True, 1, 1), (True, 4, 2), (True, 2, 5)):
+        m = O.Mog2(rows, cols, 3)
+        el, busy, got = O.pipeline_run(m, frames, 0, n, 0.01, p, t_front=tf, t_mid=tm, pipelined=pipelined)
+        assert got == want, (pipelined, tf, tm)
+        assert el > 0 and all(b > 0 for b in busy)
+        a, b = m.state(), ref.state()
+        assert all(np.array_equal(x, y, equal_nan=x.dtype.kind == "f") for x, y in zip(a, b))
+    # the pool wraps: frame i = frames[(first + i) % len]
+    m = O.Mog2(rows, cols, 3)
+    _, _, got = O.pipeline_run(m, frames[:5], 0, 5, 0.01, p, 2, 2, True)
+    _, _, got2 = O.pipeline_run(m, frames[:5], 2, 4, 0.01, p, 2, 2, True)
+    ref2 = O.Mog2(rows, cols, 3)
+    want2 = [O.chain_step(ref2, frames[i], 0.01, p)[0] for i in (0, 1, 2, 3, 4, 2, 3, 4, 0)]
+    assert got + got2 == want2
+    # GREY chain
+    grey = [f[..., 1].copy() for f in frames]
+    pg = O.hsv_params(h_lo=120, h_hi=256, erode=0, dilate=3, min_area=2.0, max_area=1e5)
+    refg = O.Mog2(rows, cols, 1)
+    wantg = [O.chain_step(refg, f, 0.01, pg)[0] for f in grey]
+    mg = O.Mog2(rows, cols, 1)
+    assert O.pipeline_run(mg, grey, 0, n, 0.01, pg, 3, 2, True)[2] == wantg
