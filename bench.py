@@ -243,9 +243,9 @@ def cpu_baseline_one(wl, frames_seq, budget_s):
     # per-stage milliseconds of the best sequential leg, and the pipelined legs
     _, _, _, seq_stage = cpu_time_pipeline(wl, frames_seq, best, best, False, budget_s / 12, 300)
     pipe = {}
-    half = max(1, best // 2)
-    for tf, tm in sorted({(half, half), (best, half), (best, best), (max(1, min(2 * best, hw // 2)), best)}):
-        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 8, 2000)
+    half, quarter = max(1, best // 2), max(1, best // 4)
+    for tf, tm in sorted({(quarter, half + quarter), (half, half), (half, best), (half, best + half), (best, half)}):
+        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 10, 2000)
         pipe[f"{tf}+{tm}+1"] = dict(value=fps, frames=n, seconds=el, stage_ms=st)
     pbest = max(pipe, key=lambda k: pipe[k]["value"])
     v_seq, v_pipe = legs[best]["value"], pipe[pbest]["value"]
@@ -261,6 +261,35 @@ def cpu_baseline_one(wl, frames_seq, budget_s):
                 pipelined={k: dict(value=v["value"], stage_ms=v["stage_ms"]) for k, v in pipe.items()},
                 pipelined_best=pbest,
                 value_1thread=f1, sample_1thread=f"{n1} frames, {el1:.1f} s, 1 thread")
+
+
+def cpu_time_streams(wl, n_streams, frames_seq, t_front, t_mid, budget_s):
+    """Aggregate frames/s of n_streams INDEPENDENT cameras on this host at once -- the reference's N-camera shape, one
+    component chain per camera (examples/two-gige/two-gige.sh:7-8): every stream its own model and its own three-stage
+    pipeline (oracle/pipeline.c) with t_front + t_mid + 1 threads, all streams concurrently -- so the contour followers
+    of different streams run in parallel (`cpu_all`)."""
+    import threading
+    import oracle_lib as O
+    p = oracle_params(wl)
+    L = len(frames_seq)
+    mogs = [oracle_mog(wl) for _ in range(n_streams)]
+    for m in mogs:
+        O.pipeline_run(m, frames_seq, 0, 2, ALPHA, p, t_front, t_mid, True, keep=False)
+    el, _, _ = O.pipeline_run(mogs[0], frames_seq, 2 % L, 3, ALPHA, p, t_front, t_mid, True, keep=False)   # one stream alone: calibration
+    n = int(max(3, min(400, budget_s / max(el / 3 * n_streams / 4, 1e-6))))
+    times = [0.0] * n_streams
+
+    def one(i):
+        times[i] = O.pipeline_run(mogs[i], frames_seq, 5 % L, n, ALPHA, p, t_front, t_mid, True, keep=False)[0]
+    th = [threading.Thread(target=one, args=(i,)) for i in range(n_streams)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    return dict(value=n_streams * n / wall, unit="frames/s aggregate", streams=n_streams, frames_per_stream=n, seconds=wall,
+                threads_per_stream=f"{t_front}+{t_mid}+1", fps_per_stream=n / max(times))
 
 
 def cpu_baseline(name, frames_seq):
@@ -283,11 +312,22 @@ def cpu_baseline(name, frames_seq):
                              by_threads=r["by_threads"], pipelined=r["pipelined"], stage_ms_sequential=r["stage_ms_sequential"],
                              sample=r["sample"])
     out["other_sizes"] = others
+    # configs[3]'s per-GPU shard on the CPU: 8 x 1080p cameras at once (every stream its own pipeline, contours in parallel)
+    try:
+        w = WORKLOADS["1080p8"]
+        st = SyntheticStream(w["rows"], w["cols"], 0, n_discs=2)
+        fr = [st.frame(t, with_discs=t > 0) for t in range(4)]
+        hw = os.cpu_count() or 1
+        per = max(1, hw // (2 * w["streams"]) // 2)          # row workers per stage and stream: half the hardware threads in all
+        out["multi_stream_1080p8"] = cpu_time_streams(w, w["streams"], fr, per, per, 5.0)
+    except Exception as e:
+        out["multi_stream_1080p8"] = dict(error=str(e)[-200:])
     return out
 
 
 LAB_CALM = False
 DENSE_NOISE = 5       # amplitude of the dense leg's per-frame noise (--dense-noise)
+EARLY_BLOB = None     # None: the library's default (on); False / True: oatgpu_set_early_blob (--early-blob)
 FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 
@@ -368,6 +408,8 @@ class Leg:
         torch.cuda.synchronize()
         self.hp = make_hotpath(wl, dev_index, dense=dense)
         self.hp.set_fusion(FUSION)
+        if EARLY_BLOB is not None:
+            self.hp.set_early_blob(EARLY_BLOB)
         self.step = 0                    # frames consumed so far
         self.input_mode = input_mode
         self.host_pool = None
@@ -616,6 +658,9 @@ def pmc_child(args):
     """Child of a rocprofv3 --pmc pass: the plain K1-bearing loop, nothing else."""
     torch.cuda.set_device(0)
     leg = Leg(args.workload, 0, 0, dense=args.dense_model, pool=10 if args.dense_model else args.pool)
+    # (the PMC passes run with --early-blob 0: rocprofv3 --pmc serialises kernel dispatches, and a blob workgroup dispatched
+    # ahead of its row scan would wait for a kernel that cannot start -- oatgpu_set_early_blob; the per-pixel kernel
+    # these passes count is not affected)
     leg.init()
     leg.age(args.age)
     leg.run(args.warmup)
@@ -635,7 +680,7 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
     cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--steps", str(K), "--warmup", str(W),
            "--age", str(AGE if not dense else 60), "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA),
-           "--fusion", str(FUSION)]
+           "--fusion", str(FUSION), "--early-blob", "0"]
     if dense:
         cmd.append("--dense-model")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -880,10 +925,14 @@ def main():
     ap.add_argument("--fusion", type=int, default=2, choices=[1, 2],
                     help="frames per launch of the fused per-pixel kernel on the pipelined path (oatgpu_set_fusion): 2 = "
                          "two consecutive frames on one pass over the model (the library's default), 1 = one launch a frame")
+    ap.add_argument("--early-blob", type=int, default=None, choices=[0, 1],
+                    help="oatgpu_set_early_blob: 1 (the library's default) = the blob workgroup of a step is dispatched ahead "
+                         "of its row scan and waits for it on the device; 0 = the plain launch order (A/B, PMC passes)")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
-    global ALPHA, RESTORE, AGE, LAB_CALM, FUSION, DENSE_NOISE
+    global ALPHA, RESTORE, AGE, LAB_CALM, FUSION, DENSE_NOISE, EARLY_BLOB
+    EARLY_BLOB = None if args.early_blob is None else bool(args.early_blob)
     DENSE_NOISE = args.dense_noise
     FUSION = args.fusion
     AGE = args.age

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, a failed pipelined launch is fatal for its context */
+#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, a failed pipelined launch is fatal for its context */
 
 enum {
     OATGPU_OK = 0,
@@ -182,6 +182,15 @@ int oatgpu_synchronize(oatgpu_ctx *ctx);
  * While a traffic audit is on (oatgpu_traffic_audit) GREY contexts launch one frame at a time. */
 int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
+/* Early dispatch of the blob-analysis workgroup (default on).  On the pipelined device-frame path the single big workgroup
+ * that labels a frame's mask (findContours + moments, DetectorFunc.cpp:41-63) is submitted on a HIP stream of its own
+ * together with the frame's other kernels and WAITS ON THE DEVICE for the frame's row scan: it takes its wave slots
+ * while the per-pixel kernel of an earlier frame drains instead of queueing for them on the frame's critical path.
+ * Results are identical either way.  Switch it off (on = 0) under tools that serialise kernel dispatches -- a
+ * counter-collecting profiler (rocprofv3 --pmc) would let the waiting workgroup run before the row scan it waits for;
+ * the kernel then gives up after 100 ms and the frame is redone by the global kernels: correct, but slow. */
+int oatgpu_set_early_blob(oatgpu_ctx *ctx, int32_t on);
+
 /* Re-configure the detector between frames (what the reference's tuning GUI
  * mutates: HSVDetector.cpp:175-251). */
 int oatgpu_set_detector(oatgpu_ctx *ctx, int32_t h_lo, int32_t h_hi, int32_t s_lo, int32_t s_hi,
@@ -311,6 +320,11 @@ int oatgpu_track_collect(oatgpu_ctx *ctx, oatgpu_position *out);
  * OATGPU_E_RING_FULL from the first oatgpu_track_stage of a set when ring_depth sets are outstanding. */
 int oatgpu_track_stage(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *frame_host);
 int oatgpu_track_enqueue_staged(oatgpu_ctx *ctx, double learning_rate);
+/* How oatgpu_track_stage moves a camera's frame: 0 (default) a DMA copy (hipMemcpyAsync); 1 a small copy KERNEL that reads
+ * the frame in place over PCIe -- for frames in page-locked, mapped host memory (oatgpu_host_register'ed shared-memory
+ * segments, oatgpu_host_alloc) that are 16-byte aligned; anything else takes the DMA path.  A launch costs the host a
+ * quarter of a DMA copy's set-up, which is what an N-camera round is short of. */
+int oatgpu_set_stage_copy(oatgpu_ctx *ctx, int32_t mode);
 /* Gives up a partly staged frame set: a camera ended in the middle of a round (its SINK went END, lib/shmemdf/Source.h:187-215)
  * or a call failed after the first oatgpu_track_stage.  Waits for the copies already started (their SOURCEs may be posted
  * afterwards), registers nothing, owes no result; the next oatgpu_track_stage starts a new set.  No-op without one. */

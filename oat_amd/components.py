@@ -363,6 +363,10 @@ class HotPath(_Context):
         self._held.append(self._staged_keep)
         self._staged_keep = []
 
+    def set_stage_copy(self, mode):
+        """oatgpu_set_stage_copy: 0 = stage() copies by DMA (default), 1 = by a kernel reading the host frame in place."""
+        self._chk(self.lib.oatgpu_set_stage_copy(self.ctx, int(mode)))
+
     def stage_abort(self):
         """oatgpu_track_stage_abort: give up a partly staged set (copies already started are waited for)."""
         self._chk(self.lib.oatgpu_track_stage_abort(self.ctx))
@@ -416,6 +420,10 @@ class HotPath(_Context):
     def set_fusion(self, frames_per_launch):
         """Frames per launch of the fused per-pixel kernel on the pipelined path: 1 or 2 (default 2)."""
         self._chk(self.lib.oatgpu_set_fusion(self.ctx, int(frames_per_launch)))
+
+    def set_early_blob(self, on=True):
+        """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan (default)."""
+        self._chk(self.lib.oatgpu_set_early_blob(self.ctx, 1 if on else 0))
 
     def profile(self, every=1):
         """every = 0/False: off; 1/True: time every step; N: time every Nth step."""

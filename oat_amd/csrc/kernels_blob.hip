@@ -162,9 +162,18 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // dilation (dil_k > 1) on the fly, writes the final mask (image frame zeroed,
 // as cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start
 // x of the run entering every word, and initialises the union-find at run heads.
-template <bool ERODE>
+// SIGNAL (r04, "Early dispatch" below): what k_blob_lds reads of this kernel's output -- fin, trans, wpre, rowinfo -- is
+// stored with agent-scope atomic stores (write-through: visible to a workgroup that is already running on another XCD,
+// whose L2 is not coherent with this one's for plain stores), and the LAST workgroup of a stream to arrive publishes
+// `ticket` in b.ready[s]: the frame's row scan is complete.
+template <typename T> __device__ __forceinline__ void st_pub(T *p, T v, bool signal)
+{
+    if (signal) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool ERODE, bool SIGNAL = false>
 __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                 int first_stream, int clear_lds_ok)
+                                                 int first_stream, int clear_lds_ok, unsigned ticket = 0u)
 {
     extern __shared__ u64 er[];
     const int lane = threadIdx.x & 63;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
         }
         __syncthreads();
     }
-    if (y >= g.H) return;
+    if (y < g.H) {
     const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     u64 *morph = b.morph + woff;
     u64 *fin = b.fin + woff;
@@ -254,10 +263,10 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             if (lane >= o) incl += v;
         }
         if (active) {
-            fin[w] = F;
-            trans[w] = T;
+            st_pub(fin + w, F, SIGNAL);
+            st_pub(trans + w, T, SIGNAL);
             carry[w] = cin;
-            wpre[w] = (unsigned short)min(runs_before + incl - cntT, 65535u);
+            st_pub(wpre + w, (unsigned short)min(runs_before + incl - cntT, 65535u), SIGNAL);
         }
         keepT = T; keepF = F;
         runs_before += __shfl(incl, 63);
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     // belong to the OUTSIDE component: hang them under root 0 right away -- on ordinary frames
     // this removes the H-long merge chain of full-width background runs.  Foreground run heads
     // get their Green accumulators cleared here.
-    if (lane == 0) b.rowinfo[(size_t)s * g.H + y] = row_fg ? (int)runs_before : 0;
+    if (lane == 0) st_pub(b.rowinfo + (size_t)s * g.H + y, row_fg ? (int)runs_before : 0, SIGNAL);
     const int last_start = chunk_carry;          // start x of the row's last run
     long long *acc = b.acc + (size_t)s * g.Palloc * 3;
     for (int c0 = 0; c0 < g.words; c0 += 64) {
@@ -293,6 +302,21 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             const int head = y * g.Wp + sx;
             parent[head] = (sx == 0 || sx == last_start) ? 0 : head;
             if ((F >> i) & 1ull) { acc[(size_t)head * 3] = 0; acc[(size_t)head * 3 + 1] = 0; acc[(size_t)head * 3 + 2] = 0; }
+        }
+    }
+    }       // y < g.H
+    if (SIGNAL) {
+        // every store of this workgroup has been acknowledged (the published arrays were written through), then ONE
+        // arrival per workgroup; the last arriver of the stream re-arms the counter and publishes the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&b.rs_done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {
+                __hip_atomic_store(&b.rs_done[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (relaxed: no cache maintenance -- every published store above was written through and acknowledged)
+                __hip_atomic_store(&b.ready[s], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -677,9 +701,24 @@ __device__ __forceinline__ void lds_union(int *par, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, double min_area, double max_area,
-                                                        ResultRec *results, int first_stream, int spec)
+// Early dispatch (r04).  Beside the per-pixel kernel this kernel's one big workgroup used to WAIT ~55 us for 16 free wave
+// slots on one compute unit (above) -- after its row scan had finished, i.e. on the frame's critical path.  With
+// wait_ticket != 0 the launch sits on a HIP stream of its own and is submitted together with the frame's other kernels,
+// long before the row scan runs: the workgroup takes its slots whenever the device has them (at the latest when the
+// running per-pixel launch drains, one launch before it is needed), parks -- one lane polls b.ready[s] between
+// s_sleeps, the other waves sit in the barrier and issue nothing; 16 of the chip's 8 192 wave slots -- and starts the
+// moment k_rowscan's last workgroup publishes the ticket.  Should the ticket not come within kWaitTicks (a tool that
+// serialises kernels, e.g. a counter-collecting profiler, makes the row scan wait for THIS kernel) the frame is
+// declined like one that is too busy: the global kernels take it.
+constexpr long long kWaitTicks = 10000000ll;         // 100 ms of the 100 MHz wall clock
+template <typename T> __device__ __forceinline__ T ld_pub(const T *p)
 {
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, double min_area, double max_area,
+                                                        ResultRec *results, int first_stream, int spec, unsigned wait_ticket)
+{
+    __shared__ int wait_failed;
     __shared__ unsigned short rows[kLdsRows + 1];        // dirty row r -> image row
     __shared__ unsigned rptr[kLdsRows + 2];              // dirty row r -> its first node
     __shared__ unsigned short rstart[kLdsRuns + 2];      // node -> start x
@@ -707,6 +746,29 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
 #else
 #define TK()
 #endif
+    if (wait_ticket) {
+        if (t == 0) {
+            int bad = 0;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(&b.ready[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_ticket) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > kWaitTicks) { bad = 1; break; }
+            }
+            wait_failed = bad;
+        }
+        __syncthreads();
+        if (wait_failed) {
+            if (t == 0) {
+                b.lds_ok[s] = 0u;
+                if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; results[s] = r; }
+            }
+            return;
+        }
+        // No acquire fence here: it is an L2 invalidate per wave, 16 per workgroup, on an XCD whose L2 the per-pixel kernel is
+        // streaming through (measured: 4K per-pixel launch 104 -> 108 us, 16 x 1080p 403 -> 491 us).  Instead every load
+        // of the row scan's arrays below is an agent-scope load (ld_pub): it is served by the memory side, where the row
+        // scan's write-through stores are, whatever this XCD's L2 or this unit's L1 hold of an earlier frame.
+    }
     TK();
     // ---- A: dirty rows and their run counts, in order (each thread owns a stretch of consecutive rows) ----
     const int per = (g.H + kLdsBlock - 1) / kLdsBlock;
@@ -717,11 +779,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
     int ric[4] = {0, 0, 0, 0};
     if (per <= 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int y = y0 + q; if (y < y1) ric[q] = rowinfo[y]; }
+        for (int q = 0; q < 4; ++q) { const int y = y0 + q; if (y < y1) ric[q] = ld_pub(rowinfo + y); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (ric[q]) { d++; rn += (unsigned)ric[q]; }
     } else {
-        for (int y = y0; y < y1; ++y) { const int ri = rowinfo[y]; if (ri) { d++; rn += (unsigned)ri; } }
+        for (int y = y0; y < y1; ++y) { const int ri = ld_pub(rowinfo + y); if (ri) { d++; rn += (unsigned)ri; } }
     }
     unsigned di = d, ri_ = rn;                          // inclusive scans over the wave
 #pragma unroll
@@ -762,7 +824,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
         }
     } else {
         for (int y = y0; y < y1; ++y) {
-            const int ri = rowinfo[y];
+            const int ri = ld_pub(rowinfo + y);
             if (ri) { rows[dbase] = (unsigned short)y; rptr[dbase] = 1u + rbase; dbase++; rbase += (unsigned)ri; }
         }
     }
@@ -783,8 +845,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
                 const unsigned r = ic / (unsigned)g.words, w = ic - r * (unsigned)g.words;
                 rr[u] = r;
                 gi[u] = (size_t)rows[r] * g.words + w;
-                T[u] = trans[gi[u]];
-                pre[u] = wpre[gi[u]];
+                T[u] = ld_pub(trans + gi[u]);
+                pre[u] = ld_pub(wpre + gi[u]);
                 if (i >= total) T[u] = 0ull;
             }
 #pragma unroll
@@ -923,9 +985,9 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, d
             const bool hp = w > 0, hn = w + 1 < g.words;
             u64 m0 = 0ull, mP = 0ull, mN = 0ull;
             if (role < 3) {
-                m0 = fin[rbase + w];
-                mP = hp ? fin[rbase + w - 1] : 0ull;
-                mN = hn ? fin[rbase + w + 1] : 0ull;
+                m0 = ld_pub(fin + rbase + w);
+                mP = hp ? ld_pub(fin + rbase + w - 1) : 0ull;
+                mN = hn ? ld_pub(fin + rbase + w + 1) : 0ull;
             }
             const int quad = lane & ~(lpr - 1);
             const u64 cur = __shfl(m0, quad), curP = __shfl(mP, quad), curN = __shfl(mN, quad);
@@ -1064,12 +1126,39 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
                            dil_k, b, first_stream, clear);
     if (lds_able && mode != kBlobGlobal)
         hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, min_area, max_area, results,
-                           first_stream, mode == kBlobSpec ? 1 : 0);
+                           first_stream, mode == kBlobSpec ? 1 : 0, 0u);
     if (mode == kBlobSpec) return;
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
                            first_stream);
     // (grid of at least one workgroup even for H <= 2: the last-arriver logic writes the result)
+    const int nw = (g.H > 2 ? (g.H - 2) * g.words : 1) * kGreenChunks;
+    hipLaunchKernelGGL(k_green_select, dim3((nw + kGreenBlock - 1) / kGreenBlock, n_streams), dim3(kGreenBlock), 0, st, g, b,
+                       min_area, max_area, results, first_stream);
+}
+
+void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
+                           int n_streams, unsigned ticket, hipStream_t st)
+{
+    if (ero_k > 1)
+        hipLaunchKernelGGL((k_rowscan<true, true>), dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
+                           st, g, src_bits, ero_k, dil_k, b, first_stream, 0, ticket);
+    else
+        hipLaunchKernelGGL((k_rowscan<false, true>), dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
+                           dil_k, b, first_stream, 0, ticket);
+}
+
+void launch_blob_tail(const Geom &g, const BlobBuffers &b, double min_area, double max_area, ResultRec *results,
+                      int first_stream, int n_streams, unsigned ticket, int mode, hipEvent_t rowscan_done, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, min_area, max_area, results,
+                       first_stream, mode == kBlobSpec ? 1 : 0, ticket);
+    if (mode == kBlobSpec) return;
+    // the global kernels read what the row scan stored PLAINLY (parent, carry, the accumulators): behind its kernel boundary
+    if (rowscan_done) (void)hipStreamWaitEvent(st, rowscan_done, 0);
+    if (g.H > 1)
+        hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
+                           first_stream);
     const int nw = (g.H > 2 ? (g.H - 2) * g.words : 1) * kGreenChunks;
     hipLaunchKernelGGL(k_green_select, dim3((nw + kGreenBlock - 1) / kGreenBlock, n_streams), dim3(kGreenBlock), 0, st, g, b,
                        min_area, max_area, results, first_stream);

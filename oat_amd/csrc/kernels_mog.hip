@@ -29,6 +29,8 @@
 //     out only for planes whose bits changed.  The state in HBM stays bit-identical to
 //     updating all of it (state-parity tests).
 #include "oatgpu_internal.h"
+#include <hip/hip_ext.h>
+#include <algorithm>
 #ifdef OATGPU_MEASURE
 #include <stdlib.h>
 #endif
@@ -931,11 +933,36 @@ void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st)
     hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
 }
 
+// One camera's frame out of page-locked HOST memory (a registered shared-memory segment: every load is a PCIe read) into
+// its staging slot, by a kernel instead of a DMA copy (oatgpu_set_stage_copy): a launch costs the host ~5 us where a
+// hipMemcpyAsync costs ~20 us of set-up per 6 MB frame.  A small grid -- the waves do nothing but wait for the link, and
+// the per-pixel kernel wants the slots: 4 x 16 bytes in flight per lane, 128 workgroups = 2 MB in flight.
+__global__ __launch_bounds__(256) void k_stage_copy(const nv4 *src, nv4 *dst, size_t n16, const uint8_t *src_tail, uint8_t *dst_tail, int tail)
+{
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
+        nv4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + (size_t)u * 256 < n16) v[u] = __builtin_nontemporal_load(src + i + (size_t)u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + (size_t)u * 256 < n16) __builtin_nontemporal_store(v[u], dst + i + (size_t)u * 256);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+void launch_stage_copy(const void *src_dev_visible, void *dst, size_t bytes, hipStream_t st)
+{
+    const size_t n16 = bytes / 16;
+    const int tail = (int)(bytes - n16 * 16);
+    const unsigned blocks = (unsigned)std::min<size_t>(128, (n16 + 1023) / 1024 ? (n16 + 1023) / 1024 : 1);
+    hipLaunchKernelGGL(k_stage_copy, dim3(blocks), dim3(256), 0, st, (const nv4 *)src_dev_visible, (nv4 *)dst, n16,
+                       (const uint8_t *)src_dev_visible + n16 * 16, (uint8_t *)dst + n16 * 16, tail);
+}
+
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 
 template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
-static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
+static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
 {
     const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
     unsigned lds = 0;
@@ -944,36 +971,39 @@ static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, i
     static const unsigned env_lds = getenv("OATGPU_K1_LDS") ? (unsigned)atoi(getenv("OATGPU_K1_LDS")) : 0u;
     lds = env_lds;
 #endif
-    hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, g, a, first_stream);
+    // stop != nullptr: the event rides on the dispatch packet's own completion signal (hipExtLaunchKernelGGL) -- no marker
+    // packet of its own between this launch and the next one on the stream
+    if (stop) hipExtLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, nullptr, stop, 0, g, a, first_stream);
+    else hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, g, a, first_stream);
 }
 
-void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st)
+void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
 {
     if (a.frames2) {                     // two frames a launch (never fresh; audited for BGR only: the caller's business)
         if (a.audit) {
-            launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st);
+            launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st, stop);
         } else if (a.nt_loads) {
-            if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st);
-            else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st);
+            if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st, stop);
+            else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st, stop);
         } else if (a.alphaT == 0.f && a.alphaT2 == 0.f) {      // a frozen model (Oat's default rate): mog2_mode, FROZEN
-            if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st);
-            else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st);
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st, stop);
+            else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st, stop);
         } else {
-            if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st);
-            else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st);
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st, stop);
+            else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st, stop);
         }
     } else if (a.audit) {                // (the audit counts bytes, not cache behaviour: default-policy loads)
-        if (a.channels == 1) launch_mog_ch<1, true, false, 1>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, true, false, 1>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, true, false, 1>(g, a, first_stream, n_streams, st, stop);
+        else launch_mog_ch<3, true, false, 1>(g, a, first_stream, n_streams, st, stop);
     } else if (a.nt_loads) {
-        if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st, stop);
+        else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st, stop);
     } else if (a.alphaT == 0.f && !a.fresh) {
-        if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st, stop);
+        else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st, stop);
     } else {
-        if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st);
-        else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st);
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st, stop);
+        else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st, stop);
     }
 }
 

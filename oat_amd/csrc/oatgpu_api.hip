@@ -86,6 +86,18 @@ struct oatgpu_ctx {
     bool kal_on = false;
     unsigned kal_ticket = 0;         // ticket of the next enqueued frame
     int expt = 0;
+    // Early dispatch of the blob workgroup (kernels_blob.hip): the back half of a device-frame step goes down TWO streams --
+    // every row scan on B0, everything behind it on B1 / B2 by frame parity, whose k_blob_lds is submitted with the
+    // step and waits on the device for its row scan's ticket.  Scratch sets 0 / 1 by frame parity; repairs of declined
+    // frames use set 2 on B0.
+    bool early_blob = true;
+    bool stage_kernel = false;       // oatgpu_set_stage_copy(1): oatgpu_track_stage copies with a kernel reading the host frame in place
+    bool k1_stop_event = false;      // the step's "K1 done" event rides on the last K1 launch (no marker packet on stream A)
+    int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
+    unsigned bh_ticket[kNB] = {};
+    hipEvent_t ev_blob[kNB] = {}, ev_rs[kNB] = {};   // scratch set q: its latest reader is done / its latest row scan is done
+    bool ev_blob_valid[kNB] = {};
+    std::vector<char> slot_st;       // per ring slot: B stream its result event was recorded on / its repair goes to
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
     std::vector<char> slot_filtered;                  // [ring_slots] was the position filter applied to this slot?
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
@@ -353,11 +365,14 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
         hipFree(b.roots); hipFree(b.nroots); hipFree(b.wpre); hipFree(b.rowinfo); hipFree(b.lds_ok);
+        hipFree(b.ready); hipFree(b.rs_done);
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
+        if (c->ev_blob[q]) hipEventDestroy(c->ev_blob[q]);
+        if (c->ev_rs[q]) hipEventDestroy(c->ev_rs[q]);
     }
     for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto e : c->ring_ev) hipEventDestroy(e);
@@ -449,7 +464,12 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     c->ring_slots = cfg->ring_depth;                  // slot = threshold buffer, slot % nb = scratch set / stream
     for (int q = 0; q < c->nb && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;
+        if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+        if (ok) ok = hipEventCreateWithFlags(&c->ev_rs[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
+    if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e) != 0;
+    if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0;
+
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
     A((void **)&c->frames, n * npx * cfg->channels);
@@ -474,6 +494,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         A((void **)&b.wpre, n * (size_t)g.H * g.words * sizeof(unsigned short));
         A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
         A((void **)&b.lds_ok, n * sizeof(unsigned));
+        A((void **)&b.ready, n * sizeof(unsigned));
+        A((void **)&b.rs_done, n * sizeof(unsigned));
     }
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
@@ -488,6 +510,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         c->slot_filtered.assign(c->ring_slots, 0);
         c->slot_spec.assign(c->ring_slots + 1, 0);
         c->slot_q.assign(c->ring_slots + 1, 0);
+        c->slot_st.assign(c->ring_slots + 1, 0);
         c->slot_repair.assign(c->ring_slots + 1, 0);
         c->slot_ev.resize(c->ring_slots);
         for (int i = 0; i < c->ring_slots; ++i) c->slot_ev[i] = i;
@@ -503,6 +526,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.lds_ok, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+        if (ok && hipMemsetAsync(b.ready, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+        if (ok && hipMemsetAsync(b.rs_done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
@@ -591,6 +616,20 @@ extern "C" int oatgpu_synchronize(oatgpu_ctx *c)
     if (!c) return OATGPU_E_INVALID;
     return quiesce(c);
 }
+extern "C" int oatgpu_set_stage_copy(oatgpu_ctx *c, int32_t mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return fail(c, OATGPU_E_INVALID, "stage copy mode must be 0 (DMA) or 1 (kernel)");
+    c->stage_kernel = mode == 1;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_set_early_blob(oatgpu_ctx *c, int32_t on)
+{
+    if (!c) return OATGPU_E_INVALID;
+    c->early_blob = on != 0;
+    return OATGPU_OK;
+}
+
 extern "C" int oatgpu_set_fusion(oatgpu_ctx *c, int32_t frames_per_launch)
 {
     if (!c) return OATGPU_E_INVALID;
@@ -1132,7 +1171,18 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
         c->stream_c2 = s2;
     }
     hipStream_t cs = (c->stream_c2 && (c->staged_count & 1)) ? c->stream_c2 : c->stream_c;
-    HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, cs));
+    bool copied = false;
+    if (c->stage_kernel && ((uintptr_t)frame_host & 15u) == 0 && ((uintptr_t)(dst + (size_t)stream_ix * fb) & 15u) == 0) {
+        void *dsrc = nullptr;                   // page-locked and mapped (oatgpu_host_register / oatgpu_host_alloc)?
+        if (hipHostGetDevicePointer(&dsrc, (void *)frame_host, 0) == hipSuccess && dsrc) {
+            launch_stage_copy(dsrc, dst + (size_t)stream_ix * fb, fb, cs);
+            HIPCHK(c, hipGetLastError());
+            copied = true;
+        } else {
+            (void)hipGetLastError();            // ordinary memory: the DMA path below bounces it
+        }
+    }
+    if (!copied) HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)c->stage_slot * n + stream_ix], cs));
     c->staged[(size_t)stream_ix] = 1;
     c->staged_count++;
@@ -1244,6 +1294,14 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             if (memcmp(&rates[(size_t)i * n + s1], &rates[(size_t)i * n + s0], sizeof(Rate)) != 0) return false;
         return true;
     };
+    // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
+    // a second marker packet between two K1s on stream A)
+    hipEvent_t k1_done = nullptr;
+    if (!(c->expt & 1)) {
+        const int nbe0 = (j[0].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
+        k1_done = c->ev_k1[j[0].slot % nbe0];
+    }
+    bool k1_done_recorded = false;
     int s0 = 0;
     while (s0 < n) {
         int s1 = s0 + 1;
@@ -1258,7 +1316,10 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
                 a.thr_bits2 = thr_buf(c, j[1].slot);
                 a.alphaT2 = r2.alphaT; a.alpha12 = r2.alpha1; a.prune2 = r2.prune;
             }
-            launch_mog_fused(c->g, a, s0, s1 - s0, A);
+            const bool last = s1 == n && i + 1 == (pair ? 1 : nj);
+            const bool ride = last && c->k1_stop_event && k1_done && !ps;
+            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr);
+            k1_done_recorded = k1_done_recorded || ride;
         }
         s0 = s1;
     }
@@ -1278,21 +1339,72 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     }
     c->launched_total += (unsigned long long)nj;
 
-    // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
-    // a second marker packet between two K1s on stream A)
-    hipEvent_t k1_done = nullptr;
-    if (!(c->expt & 1)) {
-        const int nbe0 = (j[0].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
-        k1_done = c->ev_k1[j[0].slot % nbe0];
-        HIPCHK(c, hipEventRecord(k1_done, A));
-    }
+    if (k1_done && !k1_done_recorded) HIPCHK(c, hipEventRecord(k1_done, A));
 
     // Small frames are bound by the host's launch calls: the two back halves of a two-frame step
     // then go down ONE B stream behind one wait, and one ring event -- recorded behind the second -- covers both
     // results (8 runtime calls a step instead of 10): 3 x 320x240 78 k -> 108 k fps.  From about a megapixel a step on
     // the back halves are long enough to want a stream each (one 1080p stream: 45.8 k fps apart, 38.9 k fps together).
     const bool share_b = nj == 2 && (size_t)n * (size_t)c->g.P <= ((size_t)1 << 20) && !(c->expt & 1) && !c->use_graph && !c->serial;
-    for (int i = 0; i < nj; ++i) {
+    // Early dispatch of the blob workgroup: device frames (the copy streams of the host-frame path share hardware queues
+    // with B streams, and a parked workgroup would hold the copies behind it up), steps of 4 MP and more (below that the
+    // per-pixel launches are short, the wait for wave slots with them, and the step is bound by the host's launch calls,
+    // of which this path makes two more: one 1080p stream 50 k -> 37 k fps), three B streams, a frame geometry the LDS
+    // kernel takes
+    const bool early = c->early_blob && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
+                       c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
+    if (c->last_early >= 0 && c->last_early != (int)early)          // the two paths use the scratch sets from different streams
+        for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
+    c->last_early = (int)early;
+    for (int i = 0; i < nj && early; ++i) {
+        const int slot = j[i].slot, q = slot & 1;
+        hipStream_t R = c->stream_b[0], C = c->stream_b[1 + q];
+        c->b_used[0] = c->b_used[1 + q] = true;
+        ProfStep *pb = i == 0 ? ps : nullptr;
+        BlobBuffers &bb = c->bb[q];
+        // ---- B0: the row scan, behind this step's per-pixel kernel and behind the last reader of scratch set q ----
+        if (i == 0) HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
+        if (c->ev_blob_valid[q]) HIPCHK(c, hipStreamWaitEvent(R, c->ev_blob[q], 0));
+        if (pb) HIPCHK(c, hipEventRecord(pb->e[2], R));
+        const Geom &g = c->g;
+        const u64 *src = thr_buf(c, slot);
+        const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+        int ero = c->cfg.erode > 1 ? c->cfg.erode : 0;
+        if (ero && rowscan_lds_bytes(g, dil) > kRowscanLdsMax) {     // very wide rows x large dilation
+            launch_morph(g, src, bb.tmp, ero, true, 0, n, R);
+            src = bb.tmp;
+            ero = 0;
+        }
+        if (pb) HIPCHK(c, hipEventRecord(pb->e[3], R));
+        c->last_morph = (dil || ero) ? bb.morph : src;
+        c->last_fin = bb.fin;
+        unsigned ticket = ++c->bh_ticket[q];
+        if (!ticket) ticket = ++c->bh_ticket[q];
+        launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
+        const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;
+        if (mode == kBlobFull) HIPCHK(c, hipEventRecord(c->ev_rs[q], R));
+        // ---- B1 / B2: the blob workgroup, dispatched now, started by the row scan's ticket; then whatever follows ----
+        launch_blob_tail(g, bb, c->cfg.min_area, c->cfg.max_area, c->res_dev + (size_t)slot * n, 0, n, ticket, mode,
+                         mode == kBlobFull ? c->ev_rs[q] : nullptr, C);
+        HIPCHK(c, hipGetLastError());
+        c->slot_spec[slot] = mode == kBlobSpec;
+        c->slot_q[slot] = 2;                             // a repair redoes the frame in scratch set 2 ...
+        c->slot_st[slot] = 0;                            // ... on B0, in line with the row scans
+        if (c->kal_on) {
+            KalmanLaunch kl = c->kal;
+            kl.ticket = c->kal_ticket++;
+            launch_kalman(kl, c->res_dev + (size_t)slot * n, n, C);
+            HIPCHK(c, hipGetLastError());
+        }
+        c->slot_filtered[slot] = c->kal_on;
+        if (pb) HIPCHK(c, hipEventRecord(pb->e[4], C));
+        c->slot_ev[slot] = slot;
+        HIPCHK(c, hipEventRecord(c->ring_ev[slot], C));
+        HIPCHK(c, hipEventRecord(c->ev_blob[q], C));
+        c->ev_blob_valid[q] = true;
+        c->last_q = slot;
+    }
+    for (int i = 0; i < nj && !early; ++i) {
         const int slot = j[i].slot;
         // scratch set / B stream of this frame.  Host frames arrive over the copy stream: use one B stream
         // fewer then: the copy stream sits on the last B stream's hardware queue (see acquire_streams)
@@ -1325,6 +1437,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;   // (the position filter is sequential: no repairs behind it)
             c->slot_spec[slot] = mode == kBlobSpec;
             c->slot_q[slot] = (char)q;
+            c->slot_st[slot] = (char)q;
             int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode);
             if (rc) return rc;
         }
@@ -1410,7 +1523,8 @@ static bool slot_needs_global(const oatgpu_ctx *c, int slot)
 static int launch_repair(oatgpu_ctx *c, int slot)
 {
     const int q = c->slot_q[slot];
-    hipStream_t B = c->serial ? c->stream : c->stream_b[q];
+    hipStream_t B = c->serial ? c->stream : c->stream_b[(int)c->slot_st[slot]];
+    c->b_used[(int)c->slot_st[slot]] = true;
     const int rc = back_half(c, c->bb[q], thr_buf(c, slot), 0, c->cfg.n_streams, slot, B, nullptr, -1, -1, kBlobGlobal);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], B));

@@ -102,12 +102,15 @@ struct MogLaunch {
 };
 
 // --- kernels_mog.hip ---
-void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st);
+// stop: an event that becomes the launch's own completion (nullptr: none)
+void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop = nullptr);
 // plain streaming kernels for the achievable-bandwidth measurement (n16 = number of 16-byte elements)
 void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st);
 void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);
 void launch_density_probe(const uint8_t *nmodes, size_t total, unsigned *out, hipStream_t st);   // out = {live modes, samples}
-void launch_nop(hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
+void launch_nop(hipStream_t st);
+// bytes from device-visible (page-locked, mapped) host memory to device memory by a kernel; both 16-byte aligned
+void launch_stage_copy(const void *src_dev_visible, void *dst, size_t bytes, hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
 void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
 // code 0: BGR -> GREY, 1: GREY -> BGR, 2: HSV -> BGR (Color.h:45-51); in/out 4-byte aligned
 void launch_cvt_color(int code, const uint8_t *in, uint8_t *out, size_t npx, hipStream_t st);
@@ -152,6 +155,10 @@ struct BlobBuffers {
     unsigned short *wpre;  // [n][H*words] run starts of the row in the words before this one
     int *rowinfo;          // [n][H]       0: no foreground in the row; else its number of runs
     unsigned *lds_ok;      // [n]          1: k_blob_lds wrote this frame's result, k_merge / k_green_select stand down
+    // the early blob workgroup (kernels_blob.hip "Early dispatch"): k_rowscan's last workgroup of a stream publishes the
+    // frame's ticket, the k_blob_lds workgroup that was dispatched ahead of it waits for exactly that ticket
+    unsigned *ready;       // [n]          ticket of the latest frame whose row scan is complete
+    unsigned *rs_done;     // [n]          arrival counter of k_rowscan's workgroups
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -197,5 +204,13 @@ enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
 constexpr int kNeedsGlobal = -2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
+// The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan, which publishes `ticket`
+// when its last workgroup is through, and everything behind it, whose k_blob_lds workgroup may be dispatched long before
+// the row scan has run and waits for `ticket` on the device.  ticket != 0.  The caller orders st_tail behind the row
+// scan with an event before launch_blob_tail's global kernels may run (mode kBlobFull: pass that event, else nullptr).
+void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
+                           int n_streams, unsigned ticket, hipStream_t st);
+void launch_blob_tail(const Geom &g, const BlobBuffers &b, double min_area, double max_area, ResultRec *results,
+                      int first_stream, int n_streams, unsigned ticket, int mode, hipEvent_t rowscan_done, hipStream_t st_tail);
 
 }  // namespace oatgpu

@@ -88,6 +88,7 @@ SIGNATURES = {
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
     "oatgpu_cvt_color": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p, _u8p]),
     "oatgpu_set_fusion": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_set_early_blob": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_set_homography": (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_double)]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "oatgpu_track_stage": (C.c_int, [_ctx, C.c_int32, _u8p]),
     "oatgpu_track_enqueue_staged": (C.c_int, [_ctx, C.c_double]),
     "oatgpu_track_stage_abort": (C.c_int, [_ctx]),
+    "oatgpu_set_stage_copy": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_track_ready": (C.c_int, [_ctx]),
     "oatgpu_read_mask": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p]),
     "oatgpu_mog_get_state": (C.c_int, [_ctx, C.c_int32, _u8p, _fp, _fp, _fp, C.POINTER(C.c_int32)]),

@@ -102,6 +102,7 @@ public:
     std::string model_file_;        // --model-file: resume the MOG2 model(s) from / checkpoint to this file
     std::string mask_file_;         // --mask: `framefilt mask` fused in front of mog (FrameMasker.cpp:45-75)
     bool grey_{false};              // --thresh: GREY frames, mog -> posidet thresh
+    int stage_copy_{0};             // --stage-copy kernel: oatgpu_set_stage_copy(1)
     bool homography_on_{false};     // --homography: `posifilt homography` behind the detector / the position filter
     double homography_[9]{1, 0, 0, 0, 1, 0, 0, 0, 1};
     ~BatchedTracker() override
@@ -158,6 +159,7 @@ protected:
             for (int s = 0; s < n_; ++s) gpu_.check(oatgpu_set_roi_mask(gpu_.ctx, s, m.px.data()));
         }
         if (kalman_) gpu_.check(oatgpu_set_kalman(gpu_.ctx, 1, dt_, timeout_, sig_accel_, sig_noise_));
+        if (stage_copy_) gpu_.check(oatgpu_set_stage_copy(gpu_.ctx, stage_copy_));
         if (homography_on_) gpu_.check(oatgpu_set_homography(gpu_.ctx, 1, homography_));
         for (int s = 0; s < n_; ++s) {
             position_sinks_[s].bind(sink_addresses_[s], sink_addresses_[s]);
@@ -265,7 +267,7 @@ int main(int argc, char **argv)
         if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
-                         "       [--gpu-index N | N0,N1,..] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm]\n"
+                         "       [--gpu-index N | N0,N1,..] [--ring D] [--model-file FILE] [-f|--mask FILE.pgm] [--stage-copy dma|kernel]\n"
                          "       [--thresh [lo,hi]]   GREY SOURCEs: framefilt mog -> posidet thresh instead of the HSV chain\n"
                          "       [--homography [h11,h12,...,h33]]   posifilt homography fused in (positions in world units)\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
@@ -274,7 +276,7 @@ int main(int argc, char **argv)
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography"}, {"kalman"});
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy"}, {"kalman"});
         const std::vector<std::string> sources = split_list(o.positional[0]), sinks = split_list(o.positional[1]);
         if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
         // --gpu-index N | N0,N1,...: one shard of the SOURCE list per listed device (contiguous blocks)
@@ -308,6 +310,10 @@ int main(int argc, char **argv)
             t->cfg_.ring_depth = (int)o.num("ring", 2, 1, 64);
             if (o.has("model-file")) t->model_file_ = o.kv["model-file"];
             if (o.has("mask")) t->mask_file_ = o.kv["mask"];
+            if (o.has("stage-copy")) {
+                if (o.kv["stage-copy"] == "kernel") t->stage_copy_ = 1;
+                else if (o.kv["stage-copy"] != "dma") throw std::runtime_error("--stage-copy: expected dma or kernel");
+            }
             t->kalman_ = o.has("kalman");
             t->homography_on_ = o.arr9("homography", t->homography_);
             t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)

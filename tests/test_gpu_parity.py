@@ -1152,17 +1152,24 @@ def test_input_consumed_per_stream(A):
         assert hp.collect() == ref.track(frames), t
 
 
-def test_stage_camera_by_camera_equals_enqueue(A):
+@pytest.mark.parametrize("stage_copy", [0, 1])
+def test_stage_camera_by_camera_equals_enqueue(A, stage_copy):
     """oatgpu_track_stage / oatgpu_track_enqueue_staged: the host-frame path camera by camera (any order, each camera's
     buffer reusable after its own input_consumed_stream) gives what oatgpu_track_enqueue gives; a set cannot be
-    registered before it is complete, a stream cannot be staged twice, and enqueue() is refused while a set is open."""
+    registered before it is complete, a stream cannot be staged twice, and enqueue() is refused while a set is open.
+    stage_copy = 1 (oatgpu_set_stage_copy, r04): the frames are moved by a copy KERNEL that reads page-locked host memory
+    in place -- two cameras hand over page-locked frames (rows x cols chosen so that a frame is not a multiple of 16
+    bytes: the kernel's tail), the third ordinary memory, which silently takes the DMA path."""
+    import torch
     rows, cols, n = 90, 170, 3
     from oat_amd.synth import SyntheticStream, disc_hsv_window
     kw = dict(n_streams=n, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
     hp = A.HotPath(rows, cols, ring_depth=2, **kw)
+    hp.set_stage_copy(stage_copy)
     ref = A.HotPath(rows, cols, **kw)
     streams = [SyntheticStream(rows, cols, 80 + s, n_discs=1, radius=9) for s in range(n)]
-    bufs = [np.empty((rows, cols, 3), np.uint8) for _ in range(n)]
+    pinned = [torch.empty((rows, cols, 3), dtype=torch.uint8).pin_memory() for _ in range(n - 1)]
+    bufs = [t.numpy() for t in pinned] + [np.empty((rows, cols, 3), np.uint8)]
     want = []
     for t in range(9):
         frames = [st.frame(t, with_discs=t > 0) for st in streams]
@@ -1258,6 +1265,68 @@ def test_back_half_speculation_and_repair(A):
         for s in range(n):
             want = O.chain_step(orc[s], f[s], 0.01, p)[0]
             _same_detection(got[t][s], want, (t, s, pattern[t]))
+
+
+@pytest.mark.parametrize("fusion,ring,kalman", [(2, 4, False), (1, 2, False), (2, 3, True)])
+def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
+    """Early dispatch of the blob workgroup (r04; oatgpu_set_early_blob, kernels_blob.hip): on the pipelined device-frame path
+    the k_blob_lds workgroup of a frame is submitted on its own stream ahead of the frame's row scan and waits on the
+    device for the row scan's ticket.  Frames big enough to take that path (>= 4 MP a step), quiet and BUSY ones in every
+    pattern a ring can see (busy = declined by the LDS kernel -> repaired by the global kernels in scratch set 2; then the
+    full launch sequence until the streak is back), with and without two frames a launch and with the position filter
+    (never speculative): every result equals the plain path's and the oracle's, the threshold masks too."""
+    import torch
+    rows, cols, n = 1080, 1920, 2                                   # 2 x 2.07 MP = 4.15 MP a step
+    rng = np.random.default_rng(31 + fusion + ring)
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    kw = dict(n_streams=n, ring_depth=ring, adaptation_coeff=0.01, erode=3, dilate=5, area=(20.0, 1e6), **win)
+    hp, ref = A.HotPath(rows, cols, **kw), A.HotPath(rows, cols, **kw)
+    ref.set_early_blob(False)
+    for h in (hp, ref):
+        h.set_fusion(fusion)
+        if kalman:
+            h.set_kalman(True, dt=0.02, timeout=1.0, sigma_accel=5.0, sigma_noise=1.0)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=20.0, max_area=1e6)
+    orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    base = rng.integers(90, 150, (n, rows, cols, 3)).astype(np.int16)
+
+    def frame(t, busy):
+        f = np.clip(base + rng.integers(-5, 6, base.shape), 0, 255).astype(np.uint8)
+        if t > 0:
+            for s_ in range(n):
+                cy, cx = 40 + (7 * t + 30 * s_) % 900, 50 + (11 * t + 40 * s_) % 1700
+                f[s_, cy:cy + 30, cx:cx + 45] = (255, 64, 0)
+                if busy:                                             # specks of the blob colour: far more than 3 072 runs
+                    f[s_][rng.random((rows, cols)) < 0.01] = (255, 64, 0)
+        return f
+    pattern = [0] * 5 + [1, 0, 0, 1, 1, 0] + [0] * 18 + [1] + [0] * 2
+    frames = [frame(t, b) for t, b in enumerate(pattern)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+
+    def run(h):
+        out = []
+        for d in dev:
+            h.enqueue_dev(d.data_ptr(), keepalive=d)
+            if h.outstanding() >= ring:
+                out.append(h.collect())
+        while h.outstanding():
+            out.append(h.collect())
+        return out
+    got, plain = run(hp), run(ref)
+    assert len(got) == len(frames) and got == plain
+    if not kalman:
+        for t, f in enumerate(frames):
+            for s_ in range(n):
+                _same_detection(got[t][s_], O.chain_step(orc[s_], f[s_], 0.01, p)[0], (t, s_, pattern[t]))
+    for s_ in range(n):
+        assert (hp.read_mask(A.ffi.TAP_MORPH, s_) == ref.read_mask(A.ffi.TAP_MORPH, s_)).all()
+        assert (hp.read_mask(A.ffi.TAP_FINAL, s_) == ref.read_mask(A.ffi.TAP_FINAL, s_)).all()
+    # ... and both paths in ONE context, switched between steps (the B streams are drained at the switch)
+    hp.set_early_blob(False)
+    hp.enqueue_dev(dev[-1].data_ptr(), keepalive=dev[-1]); hp.set_early_blob(True); hp.enqueue_dev(dev[-2].data_ptr(), keepalive=dev[-2])
+    ref.enqueue_dev(dev[-1].data_ptr(), keepalive=dev[-1]); ref.enqueue_dev(dev[-2].data_ptr(), keepalive=dev[-2])
+    assert [hp.collect(), hp.collect()] == [ref.collect(), ref.collect()]
 
 
 # ------------------------------------------- two frames a launch (temporal fusion) --
