@@ -327,7 +327,7 @@ def cpu_baseline(name, frames_seq):
 
 LAB_CALM = False
 DENSE_NOISE = 5       # amplitude of the dense leg's per-frame noise (--dense-noise)
-EARLY_BLOB = None     # None: the library's default (on); False / True: oatgpu_set_early_blob (--early-blob)
+EARLY_BLOB = None     # None: the library's default (off); False / True: oatgpu_set_early_blob (--early-blob)
 FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 
@@ -926,8 +926,9 @@ def main():
                     help="frames per launch of the fused per-pixel kernel on the pipelined path (oatgpu_set_fusion): 2 = "
                          "two consecutive frames on one pass over the model (the library's default), 1 = one launch a frame")
     ap.add_argument("--early-blob", type=int, default=None, choices=[0, 1],
-                    help="oatgpu_set_early_blob: 1 (the library's default) = the blob workgroup of a step is dispatched ahead "
-                         "of its row scan and waits for it on the device; 0 = the plain launch order (A/B, PMC passes)")
+                    help="oatgpu_set_early_blob: 1 = the blob workgroup of a step is dispatched ahead of its row scan and waits "
+                         "for it on the device (shorter back half, slower per-pixel kernel); 0 = the plain launch order (the "
+                         "library's default)")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()

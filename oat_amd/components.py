@@ -422,7 +422,7 @@ class HotPath(_Context):
         self._chk(self.lib.oatgpu_set_fusion(self.ctx, int(frames_per_launch)))
 
     def set_early_blob(self, on=True):
-        """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan (default)."""
+        """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan (opt-in)."""
         self._chk(self.lib.oatgpu_set_early_blob(self.ctx, 1 if on else 0))
 
     def profile(self, every=1):

@@ -123,9 +123,9 @@ __device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &d
 // dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
 // 0.f + d*d == d*d exactly, so the single-channel expressions below are the same numbers).
-template <int CH, int MODE, bool TUP, int FROZEN = 0>        // FROZEN: 0 a launch that learns, 1 every rate of the launch is 0, 2 ask alphaT
+template <int CH, int MODE, bool TUP, int FROZEN = 0>        // FROZEN: 0 a launch that learns, 1 every rate of the launch is 0, 2 ask frz
 __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float x0, float x1, float x2, const MogParams &P,
-                                          float alphaT, float alpha1, float prune, unsigned &dvm)
+                                          float alphaT, float alpha1, float prune, unsigned &dvm, bool frz = false)
 {
     if (MODE < c.nmodes) {                // nmodes shrinks when a mode is pruned, as in the reference loop
         float weight = alpha1 * s.w[MODE] + prune;
@@ -160,7 +160,9 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 // into ~10 more vector instructions at every fit site of the launches that learn.
                 // (2: the traffic-audit instantiations, which must count what the product kernel of the same launch moves)
                 bool dirty = true;
-                if (FROZEN == 1 || (FROZEN == 2 && alphaT == 0.f))
+                // (2: the audit follows the LAUNCHER's choice -- frz = MogLaunch::audit_frozen -- not this frame's rate: on a dense
+                // model, or when only one frame of a pair is at rate 0, the product kernel stores every fitted record)
+                if (FROZEN == 1 || (FROZEN == 2 && frz))
                     dirty = __float_as_uint(n0) != __float_as_uint(o0) || __float_as_uint(n1) != __float_as_uint(o1) ||
                             __float_as_uint(n2) != __float_as_uint(o2) || __float_as_uint(varnew) != __float_as_uint(var);
                 if (dirty) dvm |= (1u << MODE);
@@ -418,9 +420,16 @@ struct Audit {
 #ifndef OATGPU_F2_WAVES
 #define OATGPU_F2_WAVES 8
 #endif
-// ... and the one-frame instantiations (r04): streaming loads (dense models) / default policy (everyday models)
+// ... and the one-frame instantiations (r04, profiles/r04a_k1_one_frame_waves_spills_ab.txt, r04c_k1_dense_one_vs_two_frames_ab.txt).
+// Streaming loads (dense models): compiled for "7 waves" the instantiation has 90 scalar registers and NO spill (13 at 8) at
+// the same 60 vector registers -- the hardware still runs it 8 waves a SIMD (96 scalar registers a wave is what 8 waves
+// leave) -- and the same launch time within the noise: 271.1-271.4 against 271.8-272.6 us on one box, 320-326 against
+// 315-323 us on another.  Held down to 7 / 6 / 5 waves a SIMD by unused LDS: 272 / 273-311 / 280-304 us, 312-322 / 318-321 us --
+// occupancy is not what separates it from its two-frame sibling (286-294 us on that second box) either.
+// Default policy (everyday models): compiled for 7 waves the 93 + 6 scalar registers DO cost the eighth wave (112 allocated):
+// 76.2 -> 81.5 us at 4K, and 88.3 us at 6 waves -- the everyday launch lives on its occupancy; left at 8 with its 5 spills.
 #ifndef OATGPU_NT1_WAVES
-#define OATGPU_NT1_WAVES 8
+#define OATGPU_NT1_WAVES 7
 #endif
 #ifndef OATGPU_F1_WAVES
 #define OATGPU_F1_WAVES 8
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
 {
     static_assert(!FROZEN || (!AUDIT && !NTLD), "the frozen-model instantiations exist for the default-policy product kernels only");
     constexpr int kFrozenMode = AUDIT ? 2 : FROZEN ? 1 : 0;
+    const bool audit_frz = AUDIT && a.audit_frozen != 0;
     // The audited two-frame instantiation exists for BGR only (GREY audits count one-frame launches: the library does
     // not pair GREY frames while an audit is on).  Round 2's "instantiation the compiler is touchy about" was the
     // wide-store data hazard of st_rec below, root-caused in round 3.
@@ -677,7 +687,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
     PxLoop lp{false, false, nold, 0.f};
     unsigned dvm = 0;           // modes whose variance/mean changed
     bool wchg = false;          // weights changed
-    if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+    if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm, audit_frz);
     // A pixel that matched mode 0 as background never looks at another mode's variance/mean again this
     // frame (no fit test once fits is set, no shadow test on background, no new mode): what is left for
     // slots >= 1 is the weight decay of the live ones.  Everybody else is "full".
@@ -752,10 +762,10 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
     CUT(2);                          // + phase 2 loads
     int mask = 0, nnew = nold;
     if (work) {
-        mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
-        mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm);
+        mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm, audit_frz);
+        mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm, audit_frz);
+        mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm, audit_frz);
+        mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lp, x0, x1, x2, a.mp, a.alphaT, a.alpha1, a.prune, dvm, audit_frz);
 #ifdef OATGPU_CUT
         cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
         CUT(3);                      // + modes 1..4 of frame 1
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
         const float y0 = (float)b, y1 = (float)gg, y2 = (float)r;
         PxLoop lq{false, false, nold2, 0.f};
         bool wchg2 = false;
-        if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+        if (valid) mog2_mode<CH, 0, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
         const bool full2 = valid && !(lq.fits && lq.background);
         if (!kEarly2) {
             // records this lane has not seen yet: it was not full in frame 1 (so its slots >= 1 are as in memory)
@@ -834,10 +844,10 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
         }
         int mask2 = 0, nnew2 = nold2;
         if (work) {
-            mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
-            mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm);
+            mog2_mode<CH, 1, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
+            mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
+            mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
+            mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
             mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
@@ -977,8 +987,11 @@ static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, i
     else hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, g, a, first_stream);
 }
 
-void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
+void launch_mog_fused(const Geom &g, const MogLaunch &a_in, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
 {
+    MogLaunch a = a_in;
+    // what the product path below would pick for this launch (the audit instantiations count that kernel's stores)
+    a.audit_frozen = (!a.nt_loads && a.alphaT == 0.f && (a.frames2 ? a.alphaT2 == 0.f : !a.fresh)) ? 1 : 0;
     if (a.frames2) {                     // two frames a launch (never fresh; audited for BGR only: the caller's business)
         if (a.audit) {
             launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st, stop);

@@ -90,9 +90,14 @@ struct oatgpu_ctx {
     // every row scan on B0, everything behind it on B1 / B2 by frame parity, whose k_blob_lds is submitted with the
     // step and waits on the device for its row scan's ticket.  Scratch sets 0 / 1 by frame parity; repairs of declined
     // frames use set 2 on B0.
-    bool early_blob = true;
+    bool early_blob = false;         // opt-in (oatgpu_set_early_blob): it shortens a saturated pipeline's back half by ~50 us and
+                                     // costs the per-pixel kernel 4 % (one parked workgroup at 4K) to 20 % (32 of them, 16 x 1080p)
+    bool early_nopark = false;       // measurement: the early path's stream layout WITHOUT the parked workgroup (blob behind an event)
     bool stage_kernel = false;       // oatgpu_set_stage_copy(1): oatgpu_track_stage copies with a kernel reading the host frame in place
-    bool k1_stop_event = false;      // the step's "K1 done" event rides on the last K1 launch (no marker packet on stream A)
+    int k1_stop_event = -1;          // the step's "K1 done" event rides on the last K1 launch's own completion signal (no marker
+                                     // packet behind it on stream A): -1 by step size (>= 4 MP: +1..2.5 % at 4K; small steps are
+                                     // bound by the host's calls, and hipExtLaunchKernel costs more of those: one 1080p stream -3 %),
+                                     // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
     hipEvent_t ev_blob[kNB] = {}, ev_rs[kNB] = {};   // scratch set q: its latest reader is done / its latest row scan is done
@@ -468,7 +473,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         if (ok) ok = hipEventCreateWithFlags(&c->ev_rs[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e) != 0;
-    if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0;
+    if (const char *e = measure_env("OATGPU_EARLY_NOPARK")) c->early_nopark = atoi(e) != 0;
+    if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0 ? 1 : 0;
 
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
     A((void **)&c->nmodes, n * PA);
@@ -1317,7 +1323,8 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
                 a.alphaT2 = r2.alphaT; a.alpha12 = r2.alpha1; a.prune2 = r2.prune;
             }
             const bool last = s1 == n && i + 1 == (pair ? 1 : nj);
-            const bool ride = last && c->k1_stop_event && k1_done && !ps;
+            const bool ride_on = c->k1_stop_event < 0 ? (size_t)n * (size_t)c->g.P >= (size_t)4000000 : c->k1_stop_event != 0;
+            const bool ride = last && ride_on && k1_done && !ps;
             launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr);
             k1_done_recorded = k1_done_recorded || ride;
         }
@@ -1382,7 +1389,8 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         if (!ticket) ticket = ++c->bh_ticket[q];
         launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
         const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;
-        if (mode == kBlobFull) HIPCHK(c, hipEventRecord(c->ev_rs[q], R));
+        if (mode == kBlobFull || c->early_nopark) HIPCHK(c, hipEventRecord(c->ev_rs[q], R));
+        if (c->early_nopark) { HIPCHK(c, hipStreamWaitEvent(C, c->ev_rs[q], 0)); ticket = 0; }
         // ---- B1 / B2: the blob workgroup, dispatched now, started by the row scan's ticket; then whatever follows ----
         launch_blob_tail(g, bb, c->cfg.min_area, c->cfg.max_area, c->res_dev + (size_t)slot * n, 0, n, ticket, mode,
                          mode == kBlobFull ? c->ev_rs[q] : nullptr, C);

@@ -99,6 +99,10 @@ struct MogLaunch {
     unsigned long long *audit;   // nullptr, or 8 device counters: the traffic-audit instantiation runs (oatgpu_traffic_audit)
     MogParams mp;
     RangeParams rp;
+    int audit_frozen;            // (last: the product instantiations never read it, and their argument offsets stay as measured)
+                                 // audited launches: 1 when the PRODUCT launcher would have picked a frozen-model instantiation
+                                 // for this launch (launch_mog_fused: every rate 0, default-policy loads, not fresh) -- the audit
+                                 // then counts a fitted record's store only where its bits changed, as that kernel stores
 };
 
 // --- kernels_mog.hip ---

@@ -31,6 +31,7 @@
 // frames (a mono camera or `framefilt col -C GREY`; SimpleThreshold.cpp:46 requires them), the one-channel model
 // and the intensity window of SimpleThreshold.cpp:171-174 in the same fused launches.
 #include "component.hpp"
+#include <chrono>
 #include <deque>
 #include <fstream>
 #include <sched.h>
@@ -103,6 +104,7 @@ public:
     std::string mask_file_;         // --mask: `framefilt mask` fused in front of mog (FrameMasker.cpp:45-75)
     bool grey_{false};              // --thresh: GREY frames, mog -> posidet thresh
     int stage_copy_{0};             // --stage-copy kernel: oatgpu_set_stage_copy(1)
+    bool timing_{false};            // --timing: where the loop's wall clock goes, printed at exit (stderr)
     bool homography_on_{false};     // --homography: `posifilt homography` behind the detector / the position filter
     double homography_[9]{1, 0, 0, 0, 1, 0, 0, 0, 1};
     ~BatchedTracker() override
@@ -113,7 +115,21 @@ public:
                     std::cerr << name() << ": " << oatgpu_last_error(gpu_.ctx) << std::endl;
     }
 
+    // --timing: seconds spent waiting for SOURCEs, in oatgpu_track_stage, waiting for a camera's copy, posting SOURCEs,
+    // registering the set, and collecting + publishing results; rounds counted
+    double t_wait_{0}, t_stage_{0}, t_consumed_{0}, t_post_{0}, t_enqueue_{0}, t_publish_{0};
+    unsigned long long rounds_{0};
+    void print_timing() const
+    {
+        if (!timing_ || !rounds_) return;
+        const double r = 1e6 / (double)rounds_;
+        std::fprintf(stderr, "%s: %llu rounds x %d cameras; per round (us): source wait %.1f, stage calls %.1f, copy wait %.1f, "
+                             "source post %.1f, enqueue %.1f, collect+publish %.1f\n", name().c_str(), rounds_, n_, t_wait_ * r,
+                     t_stage_ * r, t_consumed_ * r, t_post_ * r, t_enqueue_ * r, t_publish_ * r);
+    }
+
 protected:
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::string model_path(int s) const { return n_total_ == 1 ? model_file_ : model_file_ + "." + std::to_string(stream_base_ + s); }
 
     // PositionDetector.cpp:40-56, for every stream
@@ -203,8 +219,12 @@ protected:
         // the upstream writers refill their segments while the later cameras are still being waited for and copied
         // (8 x 1080p: a round is the link's time, not the slowest writer's memcpy + the link's time) ----
         std::vector<Sample> samples(n_);
+        double t0 = timing_ ? now_s() : 0.0, t1;
+#define OAT_LAP(acc) do { if (timing_) { t1 = now_s(); acc += t1 - t0; t0 = t1; } } while (0)
         for (int s = 0; s < n_; ++s) {
-            if (frame_sources_[s].wait() == NodeState::END) {
+            const NodeState st = frame_sources_[s].wait();
+            OAT_LAP(t_wait_);
+            if (st == NodeState::END) {
                 // (frames of this round already staged are dropped with the round: their sources get their post, the
                 // set is never registered; frames of earlier rounds still get their tokens)
                 for (int q = (s > 0 ? s - 1 : 0); q < s; ++q) {
@@ -213,21 +233,29 @@ protected:
                 }
                 gpu_.check(oatgpu_track_stage_abort(gpu_.ctx));        // the partly staged set is given up, nothing is owed for it
                 while (!pending_.empty() && !quit) publish();
+                print_timing();
                 return 1;
             }
             const Frame &shm = *frame_sources_[s].retrieve();
             src_pins_[s].pin(shm);
             samples[s] = shm.sample();
             gpu_.check(oatgpu_track_stage(gpu_.ctx, s, shm.data()));
+            OAT_LAP(t_stage_);
             if (s > 0) {
                 gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, s - 1));
+                OAT_LAP(t_consumed_);
                 frame_sources_[s - 1].post();
+                OAT_LAP(t_post_);
             }
         }
         gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, n_ - 1));
+        OAT_LAP(t_consumed_);
         frame_sources_[n_ - 1].post();
+        OAT_LAP(t_post_);
         gpu_.check(oatgpu_track_enqueue_staged(gpu_.ctx, learning_coeff_));
+        OAT_LAP(t_enqueue_);
         pending_.push_back(std::move(samples));
+        ++rounds_;
 
         // ---- results: as early as possible when no camera has a frame waiting, otherwise when the ring is full ----
         while (!pending_.empty() && !quit) {
@@ -235,6 +263,8 @@ protected:
             if (!full && frames_waiting()) break;
             publish();
         }
+        OAT_LAP(t_publish_);
+#undef OAT_LAP
         return 0;
     }
 
@@ -263,7 +293,7 @@ int main(int argc, char **argv)
         Options o = Options::parse(argc, argv,
             {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
              {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"f", "mask"}, {"h", "help"}, {"v", "version"}},
-            {"help", "version", "kalman"});
+            {"help", "version", "kalman", "timing"});
         if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
@@ -276,7 +306,7 @@ int main(int argc, char **argv)
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy"}, {"kalman"});
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy", "timing"}, {"kalman", "timing"});
         const std::vector<std::string> sources = split_list(o.positional[0]), sinks = split_list(o.positional[1]);
         if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
         // --gpu-index N | N0,N1,...: one shard of the SOURCE list per listed device (contiguous blocks)
@@ -314,6 +344,7 @@ int main(int argc, char **argv)
                 if (o.kv["stage-copy"] == "kernel") t->stage_copy_ = 1;
                 else if (o.kv["stage-copy"] != "dma") throw std::runtime_error("--stage-copy: expected dma or kernel");
             }
+            t->timing_ = o.has("timing");
             t->kalman_ = o.has("kalman");
             t->homography_on_ = o.arr9("homography", t->homography_);
             t->dt_ = o.num("dt", 0.02, 0, 1e9);                        // KalmanFilter2D.cpp:69-85 (lower bound 0)

@@ -454,7 +454,7 @@ typedef struct {
     const int *lo, *hi;
 } chain_job;
 
-static void *chain_worker(void *arg)
+__attribute__((optimize("O3"))) static void *chain_worker(void *arg)
 {
     chain_job *j = (chain_job *)arg;
     const int cols = j->cols;
@@ -468,20 +468,31 @@ static void *chain_worker(void *arg)
         oat_inrange3(j->aux + off * 3, n, j->lo, j->hi, j->dst + off);
         return NULL;
     }
-    const int k = j->k, a = k / 2;
-    const uint8_t border = j->is_erode ? 255 : 0;
-    for (int y = j->y0; y < j->y1; y++)
-        for (int x = 0; x < cols; x++) {
-            uint8_t acc = border;
-            for (int t = 0; t < k; t++) {
-                uint8_t v;
-                if (j->stage == 1) { int xx = x - a + t; v = (xx < 0 || xx >= cols) ? border : j->src[(size_t)y * cols + xx]; }
-                else { int yy = y - a + t; v = (yy < 0 || yy >= j->rows) ? border : j->src[(size_t)yy * cols + x]; }
-                if (t == 0) acc = v;
-                else if (j->is_erode ? (v < acc) : (v > acc)) acc = v;
+    /* Rectangular erosion / dilation, separable: window [x - a, x - a + k - 1] (a = k / 2, not reflected), samples outside
+     * the image = the operation's identity (255 for min, 0 for max) -- cv::erode / cv::dilate's default border.  Written as
+     * whole-row min / max over shifted rows: the same numbers as a per-pixel window loop, in a form the compiler vectorises
+     * (r04: the per-pixel form with its border tests inside made this stage, not MOG2, the slowest of the CPU baseline). */
+    const int k = j->k, a = k / 2, is_erode = j->is_erode;
+    const uint8_t border = is_erode ? 255 : 0;
+    for (int y = j->y0; y < j->y1; y++) {
+        uint8_t *restrict d = j->dst + (size_t)y * cols;
+        memset(d, border, (size_t)cols);
+        for (int t = 0; t < k; t++) {
+            const int off = t - a;
+            if (j->stage == 1) {                       /* row pass: d[x] = op(d[x], src[y][x + off]) where x + off is inside */
+                const uint8_t *restrict srow = j->src + (size_t)y * cols;
+                const int x0 = off < 0 ? -off : 0, x1 = off > 0 ? cols - off : cols;
+                if (is_erode) { for (int x = x0; x < x1; x++) { const uint8_t v = srow[x + off]; d[x] = v < d[x] ? v : d[x]; } }
+                else          { for (int x = x0; x < x1; x++) { const uint8_t v = srow[x + off]; d[x] = v > d[x] ? v : d[x]; } }
+            } else {                                   /* column pass: d = op(d, src[y + off]) where the row exists */
+                const int yy = y + off;
+                if (yy < 0 || yy >= j->rows) continue;
+                const uint8_t *restrict srow = j->src + (size_t)yy * cols;
+                if (is_erode) { for (int x = 0; x < cols; x++) d[x] = srow[x] < d[x] ? srow[x] : d[x]; }
+                else          { for (int x = 0; x < cols; x++) d[x] = srow[x] > d[x] ? srow[x] : d[x]; }
             }
-            j->dst[(size_t)y * cols + x] = acc;
         }
+    }
     return NULL;
 }
 

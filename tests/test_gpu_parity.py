@@ -1281,6 +1281,7 @@ def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
     win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
     kw = dict(n_streams=n, ring_depth=ring, adaptation_coeff=0.01, erode=3, dilate=5, area=(20.0, 1e6), **win)
     hp, ref = A.HotPath(rows, cols, **kw), A.HotPath(rows, cols, **kw)
+    hp.set_early_blob(True)
     ref.set_early_blob(False)
     for h in (hp, ref):
         h.set_fusion(fusion)

@@ -27,6 +27,13 @@ def test_checker_sees_the_sequences_of_round_2():
     assert H.check_function("f", [(0, "global_store_dwordx4 v0, v[4:7], s[2:3]"), (8, "s_nop 0"), (12, "v_add_u32_e32 v5, 1, v9")] + tail)
     assert not H.check_function("f", [(0, "global_store_dwordx4 v0, v[4:7], s[2:3]"), (8, "v_add_u32_e32 v0, 1, v9")] + tail)
     assert not H.check_function("f", [(0, "buffer_store_dwordx2 v[0:1], v22, s[84:87], s6 offen"), (8, "v_mov_b32_e32 v1, 16")] + tail)
+    #  data in accumulator registers is data too, and is not confused with the VGPR of the same number;
+    # an indirect jump inside the window cannot be followed and counts as a hazard
+    astore = "buffer_store_dwordx4 a[0:3], v22, s[84:87], s6 offen"
+    assert H.check_function("f", [(0, astore), (8, "v_accvgpr_write_b32 a1, v9")] + tail)
+    assert not H.check_function("f", [(0, astore), (8, "v_mov_b32_e32 v1, 16")] + tail)
+    assert not H.check_function("f", [(0, store), (8, "v_accvgpr_write_b32 a1, v9")] + tail)
+    assert H.check_function("f", [(0, store), (8, "s_setpc_b64 s[4:5]")] + tail)
 
 
 @pytest.mark.skipif(not os.path.exists(H.OBJDUMP), reason="llvm-objdump of ROCm not found")

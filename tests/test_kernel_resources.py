@@ -56,6 +56,18 @@ def test_per_pixel_kernel_register_allocation():
         assert one["vgpr_count"] <= 64 and one["sgpr_spill_count"] <= 14, one
     dense = inst(3, False, True, 2, False)                        # the streaming-load instantiation: 7 waves a SIMD
     assert dense["vgpr_count"] <= 72 and dense["sgpr_spill_count"] <= 10, dense
+    # the ONE-frame instantiations (r04): what a caller that collects every frame before the next one runs, and SURVEY 8d's
+    # literal 205 B/px launch.  Everyday model: 8 waves a SIMD is what it lives on (64 vector registers, at most 96 scalar
+    # registers incl. the 6 the hardware adds: compiled for 7 waves it took 99 and lost the eighth wave -- 76 -> 81 us at 4K).
+    for frozen in (False, True):
+        one = inst(3, False, False, 1, frozen)
+        assert one["vgpr_count"] <= 64 and one["sgpr_count"] + 6 <= 96, one
+    assert inst(3, False, False, 1, False)["sgpr_spill_count"] <= 6
+    # dense model, one frame a launch: no scalar spill any more (13 in round 3), still 8 waves a SIMD in hardware
+    dense1 = inst(3, False, True, 1, False)
+    assert dense1["vgpr_count"] <= 64 and dense1["sgpr_spill_count"] == 0 and dense1["sgpr_count"] + 6 <= 96, dense1
+    for ch in (1,):                                               # GREY one-frame instantiations: 8 waves, no scratch (checked above)
+        assert inst(ch, False, False, 1, False)["vgpr_count"] <= 64 and inst(ch, False, True, 1, False)["vgpr_count"] <= 64
 
 
 @pytest.mark.skipif(not (os.path.exists(H.OBJDUMP) and os.path.exists(READELF)), reason="llvm tools of ROCm not found")

@@ -442,3 +442,30 @@ def test_pipelined_chain_equals_the_sequential_chain():
     wantg = [O.chain_step(refg, f, 0.01, pg)[0] for f in grey]
     mg = O.Mog2(rows, cols, 1)
     assert O.pipeline_run(mg, grey, 0, n, 0.01, pg, 3, 2, True)[2] == wantg
+
+
+@pytest.mark.parametrize("e,d", [(0, 10), (3, 7), (7, 7), (2, 4), (13, 1), (1, 13)])
+def test_chain_morphology_equals_the_single_stage_morphology(e, d):
+    """The chain's row-parallel, vectorised erode / dilate (oracle/contours.c chain_worker, r04) against the per-pixel
+    window form of oracle/pixels.c (oat_erode_rect / oat_dilate_rect, the one the known answers and the scipy statement
+    pin): same threshold image after morphology for odd and EVEN sizes (anchor k / 2, not reflected), blobs touching every
+    border, any number of row workers."""
+    rng = np.random.default_rng(100 * e + d)
+    rows, cols = 61, 83
+    bgr = np.zeros((rows, cols, 3), np.uint8)
+    bgr[rng.random((rows, cols)) < 0.35] = (255, 64, 0)                       # passes the window below
+    bgr[0:3, :] = (255, 64, 0); bgr[:, -2:] = (255, 64, 0); bgr[-1, 5:9] = (255, 64, 0); bgr[20:44, 0] = (255, 64, 0)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=e, dilate=d, min_area=1.0, max_area=1e9)
+    hsv = O.bgr2hsv(bgr)
+    thr = O.inrange3(hsv, (100, 150, 100), (125, 256, 256))
+    if e > 0:
+        thr = O.erode(thr, e)
+    if d > 0:
+        thr = O.dilate(thr, d)
+    want_det, want_thr = O.detect_hsv(hsv, p)
+    assert (want_thr == thr).all()
+    for nt in (1, 3, 8):
+        m = O.Mog2(rows, cols, 3)
+        got_det, got_thr = O.chain_step(m, bgr, 0.0, p, nthreads=nt)        # frame 1: MOG2 keeps every non-black pixel
+        assert (got_thr == thr).all(), (e, d, nt)
+        assert got_det == want_det

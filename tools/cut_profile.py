@@ -2,7 +2,7 @@
 """Dynamic instruction profile of the per-pixel kernel by truncation (measurement aid, LABNOTES r03).
 
     python tools/cut_profile.py save  [--dense] DIR      product library: age a 4K model as bench.py does, save it + 8 frames
-    python tools/cut_profile.py run   [--dense] DIR      (OATGPU_LIB = a -DOATGPU_CUT=n variant, under rocprofv3 --pmc
+    python tools/cut_profile.py run   [--dense] [--fusion1] DIR      (OATGPU_LIB = a -DOATGPU_CUT=n variant, under rocprofv3 --pmc
                                                           SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES): load, 24 two-frame launches
 
 A -DOATGPU_CUT=n build ends k_mog_fused at cut n with everything computed so far kept alive through one store, and
@@ -36,7 +36,8 @@ def main():
         return
     hp = bench.make_hotpath(bench.WORKLOADS["4k1"], 0, dense=dense)
     hp.load_mog_state(os.path.join(d, f"{tag}.mog"))
-    hp.set_fusion(2)
+    hp.set_fusion(1 if "--fusion1" in sys.argv else 2)     # --fusion1: the one-frame-a-launch instantiation
+    hp.set_early_blob(False)                               # rocprofv3 --pmc serialises dispatches (oatgpu_set_early_blob)
     fr = [torch.from_numpy(f).cuda() for f in np.load(os.path.join(d, f"{tag}_frames.npy"))]
     torch.cuda.synchronize()
     if dense:                      # the library picks the streaming-load instantiation from its density probes (frames 8, 16, ..)

@@ -56,7 +56,7 @@ def batched(a):
     readers = [subprocess.Popen([B("oat-posi-cout"), x], stdout=o, text=True) for x, o in zip(snks, outs)]
     tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
-                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []))
+                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []))
     time.sleep(4.0)
     t0 = time.perf_counter()
     feeders = [subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", raws[s], "--rows", str(a.rows), "--cols",
@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--cameras", type=int, default=1)
     ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--timing", action="store_true", help="oat-track-hip --timing: where the tracker's loop spends its wall clock")
     ap.add_argument("--stage-copy", default="", choices=["", "dma", "kernel"], help="oat-track-hip --stage-copy (oatgpu_set_stage_copy)")
     ap.add_argument("--feeder-node", type=int, default=-1,
                     help="keep the frame servers (and so, by first touch, the shared-memory frames) on the CPUs of this NUMA "
