@@ -276,7 +276,7 @@ def cpu_time_streams(wl, n_streams, frames_seq, t_front, t_mid, budget_s):
     for m in mogs:
         O.pipeline_run(m, frames_seq, 0, 2, ALPHA, p, t_front, t_mid, True, keep=False)
     el, _, _ = O.pipeline_run(mogs[0], frames_seq, 2 % L, 3, ALPHA, p, t_front, t_mid, True, keep=False)   # one stream alone: calibration
-    n = int(max(3, min(400, budget_s / max(el / 3 * n_streams / 4, 1e-6))))
+    n = int(max(3, min(200, budget_s / max(el / 3 * n_streams / 1.5, 1e-6))))     # (the streams slow each other down)
     times = [0.0] * n_streams
 
     def one(i):

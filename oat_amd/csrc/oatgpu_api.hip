@@ -1190,6 +1190,11 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
     }
     if (!copied) HIPCHK(c, hipMemcpyAsync(dst + (size_t)stream_ix * fb, frame_host, fb, hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)c->stage_slot * n + stream_ix], cs));
+    // Submit NOW.  ROCm 7.2 keeps a stream's queued copy back until something flushes the stream -- measured with the
+    // tracker's own clock (oat-track-hip --timing, profiles/r04g_pipeline_ncam_before_flush.txt): every camera's copy started
+    // only when the loop began to WAIT for it (its hipEventQuery), so the 8 x 112 us of link time of a round ran strictly
+    // one after the other with the host's 300 us of per-round work instead of under it.  A stream query is the flush.
+    (void)hipStreamQuery(cs);
     c->staged[(size_t)stream_ix] = 1;
     c->staged_count++;
     return OATGPU_OK;
@@ -1256,6 +1261,7 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
         if (c->per_stream_copy_ev && s + 1 < n) HIPCHK(c, hipEventRecord(c->copy_ev_s[(size_t)slot * n + s], c->stream_c));
     }
     HIPCHK(c, hipEventRecord(c->copy_ev[slot], c->stream_c));
+    (void)hipStreamQuery(c->stream_c);                    // submit the copies now (see oatgpu_track_stage)
     c->last_copy_slot = slot;
     c->last_copy_per_stream = c->per_stream_copy_ev;
     return enqueue_frames(c, dst, lr, c->copy_ev[slot]);

@@ -16,9 +16,9 @@
 //                                                     here, camera by camera, right after the DMA out of its segment
 //   collect + publish finished results                :88-96, SINK i: wait, *shared = position, post
 //
-// A result is published as soon as it is ready when no new frame is waiting (minimum latency, camera-bound
-// pipelines), and only when the ring is full otherwise (frames waiting: copy of step t+1 overlaps the
-// kernels of step t, GPU-bound pipelines).  Options are the union of the three stock components'
+// A result is published as soon as it is ready whenever the camera the loop is waiting for has no frame yet (minimum
+// latency, camera-bound pipelines); with frames waiting the loop goes on staging and finished results leave SINK by
+// SINK between the copies (the link never idles for a consumer's hand-shake), at the latest when the ring is full.  Options are the union of the three stock components'
 // (-a is mog's adaptation coefficient; the detector's area is --area).
 //
 // --gpu-index D0,D1,...  shards the cameras over several devices from THIS process (BASELINE configs 3/4 at the
@@ -186,30 +186,46 @@ protected:
         return true;
     }
 
-    // one result set (oldest outstanding) -> the SINKs, PositionDetector.cpp:88-96
-    void publish()
+    // Results leave set by set, SINK by SINK (PositionDetector.cpp:88-96 per camera): publish_some() hands out up to
+    // max_sinks tokens of the oldest outstanding result set -- with only_if_ready it never waits for the device -- so that
+    // the staging loop below can publish BETWEEN its copies: a SINK's wait() is a round trip to the consumer process
+    // (~30 us each; 8 cameras: 275 us a round), and done behind the round it was time the PCIe link sat idle
+    // (r04, `--timing`: 8 x 1080p 6.2 k -> see DESIGN.md section 6).  Order per SINK is the frames' order.
+    void publish_sink(int s)
     {
-        gpu_.check(oatgpu_track_collect(gpu_.ctx, results_.data()));
-        const std::vector<Sample> samples = std::move(pending_.front());
-        pending_.pop_front();
-        for (int s = 0; s < n_; ++s) {
-            const oatgpu_position &r = results_[s];
-            Position2D pos("");
-            pos.set_sample(samples[s]);                              // PositionDetector.cpp:80
-            pos.position_valid = r.valid != 0;
-            if (kalman_) {                                           // KalmanFilter2D.cpp:123-137
-                pos.position.x = r.x; pos.position.y = r.y;
-                pos.velocity.x = r.vx; pos.velocity.y = r.vy;
-                pos.velocity_valid = r.velocity_valid != 0;
-            } else if (r.valid) {                                    // DetectorFunc.cpp:46,58-60: x/y only when found
-                pos.position.x = r.x; pos.position.y = r.y;
-            }
-            if (homography_on_) pos.setCoordSystem(DistanceUnit::WORLD, homography_);   // HomographyTransform2D.cpp:102
-            position_sinks_[s].wait();
-            *shared_positions_[s] = pos;
-            position_sinks_[s].post();
+        const oatgpu_position &r = results_[s];
+        Position2D pos("");
+        pos.set_sample(pub_samples_[s]);                             // PositionDetector.cpp:80
+        pos.position_valid = r.valid != 0;
+        if (kalman_) {                                               // KalmanFilter2D.cpp:123-137
+            pos.position.x = r.x; pos.position.y = r.y;
+            pos.velocity.x = r.vx; pos.velocity.y = r.vy;
+            pos.velocity_valid = r.velocity_valid != 0;
+        } else if (r.valid) {                                        // DetectorFunc.cpp:46,58-60: x/y only when found
+            pos.position.x = r.x; pos.position.y = r.y;
         }
+        if (homography_on_) pos.setCoordSystem(DistanceUnit::WORLD, homography_);   // HomographyTransform2D.cpp:102
+        position_sinks_[s].wait();
+        *shared_positions_[s] = pos;
+        position_sinks_[s].post();
     }
+    void publish_some(int max_sinks, bool only_if_ready)
+    {
+        if (!collected_) {
+            if (pending_.empty()) return;
+            if (only_if_ready && oatgpu_track_ready(gpu_.ctx) != 1) return;
+            gpu_.check(oatgpu_track_collect(gpu_.ctx, results_.data()));
+            pub_samples_ = std::move(pending_.front());
+            pending_.pop_front();
+            collected_ = true;
+            pub_cursor_ = 0;
+        }
+        for (; pub_cursor_ < n_ && max_sinks > 0; ++pub_cursor_, --max_sinks) publish_sink(pub_cursor_);
+        if (pub_cursor_ == n_) collected_ = false;
+    }
+    // the set in progress to its end, or else the whole next set (waits for the device if it must)
+    void publish() { publish_some(n_, false); }
+    bool results_owed() const { return collected_ || !pending_.empty(); }
 
     int process() override
     {
@@ -222,6 +238,12 @@ protected:
         double t0 = timing_ ? now_s() : 0.0, t1;
 #define OAT_LAP(acc) do { if (timing_) { t1 = now_s(); acc += t1 - t0; t0 = t1; } } while (0)
         for (int s = 0; s < n_; ++s) {
+            // Nothing to stage yet (this camera has not delivered): results that are owed leave NOW -- the reference publishes
+            // a position as soon as it has one (PositionDetector.cpp:88-96); a frame that was only registered for a
+            // two-frame launch goes out alone (oatgpu_track_collect), which is right when the cameras are slower than
+            // the device.  With a frame waiting the loop goes on staging and the results leave between the copies.
+            while (!quit && results_owed() && !frame_sources_[s].token_waiting()) publish_some(1, collected_);
+            OAT_LAP(t_publish_);
             const NodeState st = frame_sources_[s].wait();
             OAT_LAP(t_wait_);
             if (st == NodeState::END) {
@@ -232,7 +254,7 @@ protected:
                     frame_sources_[q].post();
                 }
                 gpu_.check(oatgpu_track_stage_abort(gpu_.ctx));        // the partly staged set is given up, nothing is owed for it
-                while (!pending_.empty() && !quit) publish();
+                while (results_owed() && !quit) publish();
                 print_timing();
                 return 1;
             }
@@ -241,6 +263,9 @@ protected:
             samples[s] = shm.sample();
             gpu_.check(oatgpu_track_stage(gpu_.ctx, s, shm.data()));
             OAT_LAP(t_stage_);
+            // while this camera's copy runs: one token of a FINISHED result set to its SINK (never the newest set: asking for
+            // a frame that is only registered would launch it alone and end the two-frames-a-launch pairing)
+            if (collected_ || pending_.size() >= 2) { publish_some(1, true); OAT_LAP(t_publish_); }
             if (s > 0) {
                 gpu_.check(oatgpu_track_input_consumed_stream(gpu_.ctx, s - 1));
                 OAT_LAP(t_consumed_);
@@ -257,21 +282,12 @@ protected:
         pending_.push_back(std::move(samples));
         ++rounds_;
 
-        // ---- results: as early as possible when no camera has a frame waiting, otherwise when the ring is full ----
-        while (!pending_.empty() && !quit) {
-            const bool full = (int)pending_.size() == cfg_.ring_depth;
-            if (!full && frames_waiting()) break;
-            publish();
-        }
+        // ---- a free ring slot for the next round; everything else leaves while the loop waits for a camera (top of the
+        // loop: at once when no frame is waiting -- minimum latency) or between the next round's copies (frames waiting) ----
+        while ((int)pending_.size() == cfg_.ring_depth && !quit) publish();
         OAT_LAP(t_publish_);
 #undef OAT_LAP
         return 0;
-    }
-
-    bool frames_waiting()
-    {
-        for (int s = 0; s < n_; ++s) if (!frame_sources_[s].token_waiting()) return false;
-        return true;
     }
 
     std::string name_;
@@ -284,6 +300,9 @@ protected:
     std::vector<const uint8_t *> frame_ptrs_;
     std::vector<oatgpu_position> results_;
     std::deque<std::vector<Sample>> pending_;  // Samples of the frames whose results are still on the device
+    std::vector<Sample> pub_samples_;          // ... and of the result set that is being handed out (publish_some)
+    bool collected_{false};
+    int pub_cursor_{0};
     GpuCtx gpu_;
 };
 

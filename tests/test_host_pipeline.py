@@ -380,6 +380,30 @@ def test_batched_tracker_four_cameras_match_their_oracles(host_bins, tmp_path, r
 
 
 @pytest.mark.gpu
+def test_batched_tracker_free_running_cameras_publish_between_their_copies(host_bins, tmp_path):
+    """Free-running cameras (frames always waiting) with a ring of four: the tracker hands finished result sets out SINK
+    by SINK between the copies of the next round (oat_track_hip.cpp publish_some, r04) and pairs frames for the
+    per-pixel kernel.  One token out per token in, in order, every camera equal to ITS oracle, each token with its
+    frame's Sample."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n, ncam = 240, 320, 60, 5
+    streams = [SyntheticStream(rows, cols, 50 + s, n_discs=1, radius=8 + 2 * s) for s in range(ncam)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
+    got = _run_batched(host_bins, tmp_path, frames, ring=4, fps=0, extra=("--timing",))
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7,
+                     min_area=20.0, max_area=1e5)
+    for s in range(ncam):
+        assert len(got[s]) == n, (s, len(got[s]))
+        orc = O.Mog2(rows, cols, 3)
+        for t, (f, g) in enumerate(zip(frames[s], got[s])):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], (s, t, g)
+            if want["valid"]:
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ncam,devices", [(4, "0,0"), (3, "0,0"), (2, "0,0,0"), (16, "0,0,0,0,0,0,0,0"), (9, "0,0,0,0,0,0,0,0")])
 def test_batched_tracker_sharded_over_device_contexts(host_bins, tmp_path, ncam, devices):
     """`oat-track-hip --gpu-index D0,D1,..`: the C++ launcher of SURVEY 8e's partition -- the SOURCE list cut into

@@ -54,10 +54,11 @@ def batched(a):
     # readers write to FILES: n pipes drained one after the other would fill up and stall the whole pipeline
     outs = [open(f"/dev/shm/{x}.out", "w+") for x in snks]
     readers = [subprocess.Popen([B("oat-posi-cout"), x], stdout=o, text=True) for x, o in zip(snks, outs)]
-    tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
+    tracker = subprocess.Popen((a.tracker_prefix.split() if a.tracker_prefix else []) +
+                               [B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
                                 "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []))
-    time.sleep(4.0)
+    time.sleep(12.0 if a.tracker_prefix else 4.0)
     t0 = time.perf_counter()
     feeders = [subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", raws[s], "--rows", str(a.rows), "--cols",
                                  str(a.cols), "-n", str(a.frames)], preexec_fn=node_pin(a.feeder_node)) for s in range(n)]
@@ -90,6 +91,7 @@ def main():
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--cameras", type=int, default=1)
     ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--tracker-prefix", default="", help="command to run oat-track-hip under, e.g. 'rocprofv3 --memory-copy-trace -d /tmp/mc -o r --'")
     ap.add_argument("--timing", action="store_true", help="oat-track-hip --timing: where the tracker's loop spends its wall clock")
     ap.add_argument("--stage-copy", default="", choices=["", "dma", "kernel"], help="oat-track-hip --stage-copy (oatgpu_set_stage_copy)")
     ap.add_argument("--feeder-node", type=int, default=-1,
