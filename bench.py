@@ -854,7 +854,7 @@ def pipeline_block(device):
         try:
             # (its own process group: on a timeout the frame servers, the tracker and the readers go with it)
             pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "pipeline_fps.py"), "--rows", "1080", "--cols", "1920",
-                                   "--frames", "1200", "--fused", "--cameras", "8", "--ring", "4"], stdout=subprocess.PIPE,
+                                   "--frames", "1500", "--fused", "--cameras", "8", "--ring", "4", "--timing"], stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
                 so, se = pr.communicate(timeout=150)
@@ -865,10 +865,15 @@ def pipeline_block(device):
                 se = "timeout; " + (se or "")
             r = argparse.Namespace(stdout=so or "", stderr=se or "")
             m = re.search(r"(\d+) tokens in ([0-9.]+) s = ([0-9.]+) fps aggregate", r.stdout)
+            m2 = re.search(r"rounds 17\.\.: ([0-9.]+) fps aggregate", r.stdout)
+            m3 = re.search(r"per round \(us\): (.*?); steady", r.stdout)
             out["track_8x1080p"] = (dict(fps_aggregate=float(m.group(3)), tokens=int(m.group(1)), real_s=float(m.group(2)),
-                                         what="8 oat-frameserve-raw (free-running, 1200 frames each) -> one oat-track-hip with 8 SOURCEs "
-                                              "and 8 SINKs, ring 4 -> 8 oat-posi-cout; wall clock from the start of the frame servers "
-                                              "to the last token, process start-up included")
+                                         fps_steady=float(m2.group(1)) if m2 else None,
+                                         tracker_loop_us_per_round=m3.group(1) if m3 else None,
+                                         what="8 oat-frameserve-raw (free-running, 1500 frames each) -> one oat-track-hip with 8 SOURCEs "
+                                              "and 8 SINKs, ring 4 -> 8 oat-posi-cout; fps_aggregate: wall clock from the start of the frame "
+                                              "servers to the last token, process start-up included; fps_steady: the tracker's own clock "
+                                              "from the end of its round 16 to the end of its last round (oat-track-hip --timing)")
                                     if m else dict(error=(r.stdout + r.stderr)[-200:]))
         except Exception as e:
             out["track_8x1080p"] = dict(error=str(e)[-200:])

@@ -117,15 +117,18 @@ public:
 
     // --timing: seconds spent waiting for SOURCEs, in oatgpu_track_stage, waiting for a camera's copy, posting SOURCEs,
     // registering the set, and collecting + publishing results; rounds counted
-    double t_wait_{0}, t_stage_{0}, t_consumed_{0}, t_post_{0}, t_enqueue_{0}, t_publish_{0};
+    double t_wait_{0}, t_stage_{0}, t_consumed_{0}, t_post_{0}, t_enqueue_{0}, t_publish_{0}, t_r16_{0}, t_last_{0};
     unsigned long long rounds_{0};
     void print_timing() const
     {
         if (!timing_ || !rounds_) return;
         const double r = 1e6 / (double)rounds_;
+        // (the rate between the end of round 16 and the end of the last round: process start-up, the first frames' page
+        // registration and the models' initialisation are the harness's, not the loop's)
+        const double steady = rounds_ > 16 && t_last_ > t_r16_ ? (double)(rounds_ - 16) * n_ / (t_last_ - t_r16_) : 0.0;
         std::fprintf(stderr, "%s: %llu rounds x %d cameras; per round (us): source wait %.1f, stage calls %.1f, copy wait %.1f, "
-                             "source post %.1f, enqueue %.1f, collect+publish %.1f\n", name().c_str(), rounds_, n_, t_wait_ * r,
-                     t_stage_ * r, t_consumed_ * r, t_post_ * r, t_enqueue_ * r, t_publish_ * r);
+                             "source post %.1f, enqueue %.1f, collect+publish %.1f; steady %.1f fps aggregate\n", name().c_str(),
+                     rounds_, n_, t_wait_ * r, t_stage_ * r, t_consumed_ * r, t_post_ * r, t_enqueue_ * r, t_publish_ * r, steady);
     }
 
 protected:
@@ -281,6 +284,7 @@ protected:
         OAT_LAP(t_enqueue_);
         pending_.push_back(std::move(samples));
         ++rounds_;
+        if (timing_) { t_last_ = now_s(); if (rounds_ == 16) t_r16_ = t_last_; }
 
         // ---- a free ring slot for the next round; everything else leaves while the loop waits for a camera (top of the
         // loop: at once when no frame is waiting -- minimum latency) or between the next round's copies (frames waiting) ----

@@ -9,6 +9,7 @@ the reported rate is the aggregate over all cameras.
 """
 import argparse
 import os
+import re
 import subprocess
 import sys
 import time
@@ -54,10 +55,12 @@ def batched(a):
     # readers write to FILES: n pipes drained one after the other would fill up and stall the whole pipeline
     outs = [open(f"/dev/shm/{x}.out", "w+") for x in snks]
     readers = [subprocess.Popen([B("oat-posi-cout"), x], stdout=o, text=True) for x, o in zip(snks, outs)]
+    terr = open(f"/dev/shm/{tag}.trk.err", "w+") if a.timing else None
     tracker = subprocess.Popen((a.tracker_prefix.split() if a.tracker_prefix else []) +
                                [B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
-                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []))
+                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []),
+                               stderr=terr)
     time.sleep(12.0 if a.tracker_prefix else 4.0)
     t0 = time.perf_counter()
     feeders = [subprocess.Popen([B("oat-frameserve-raw"), srcs[s], "-f", raws[s], "--rows", str(a.rows), "--cols",
@@ -79,8 +82,22 @@ def batched(a):
     for raw in raws:
         os.unlink(raw)
     subprocess.run([B("oat-clean-hip")] + srcs + snks, capture_output=True)
+    steady = ""
+    if terr:
+        terr.seek(0)
+        txt = terr.read()
+        terr.close()
+        os.unlink(terr.name)
+        for l in txt.splitlines():
+            if "per round" in l:
+                print(l)
+                m = re.search(r"steady ([0-9.]+) fps", l)
+                if m:
+                    steady = f"; the tracker's own clock, rounds 17..: {m.group(1)} fps aggregate"
+            elif l.strip() and "Exiting" not in l:
+                print(l, file=sys.stderr)
     print(f"batched oat-track-hip, {n} cameras x {a.cols}x{a.rows}, ring {a.ring}: {tokens} tokens in {el:.2f} s = "
-          f"{tokens / el:.1f} fps aggregate, {tokens / el / n:.1f} per camera ({ok} valid positions)")
+          f"{tokens / el:.1f} fps aggregate, {tokens / el / n:.1f} per camera ({ok} valid positions){steady}")
 
 
 def main():
