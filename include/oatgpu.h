@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, a failed pipelined launch is fatal for its context */
+#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, oatgpu_set_deferred / _fetch_frame / _fetch_position, a failed pipelined launch is fatal for its context */
 
 enum {
     OATGPU_OK = 0,
@@ -242,6 +242,18 @@ int oatgpu_mask_filter(oatgpu_ctx *ctx, int32_t stream, const uint8_t *in, uint8
  * contexts, inRange [i_min, i_max] (0..256), pixels outside are zeroed.  out may equal in. */
 int oatgpu_thresh_filter(oatgpu_ctx *ctx, const uint8_t *frame_in, uint8_t *frame_out, int32_t i_min,
                          int32_t i_max);
+
+/* Deferred completion of the stage-by-stage operators below (default off).  With on = 1 a frame filter (oatgpu_mog_filter,
+ * _bsub_filter, _mask_filter, _thresh_filter, _bgr2hsv, _cvt_color) or a detector (oatgpu_detect_hsv / _thresh / _diff)
+ * returns as soon as its INPUT frame has been read -- the point where the reference posts its SOURCE, right after its
+ * memcpy (FrameFilter.cpp:73-80, PositionDetector.cpp:78-86) -- leaves its output argument untouched (it may be NULL for the
+ * detectors) and keeps the result on the device; oatgpu_fetch_frame / oatgpu_fetch_position then deliver it: a component
+ * posts its SOURCE, waits for its SINK and has the filtered frame copied STRAIGHT into the sink's (page-locked) shared-memory
+ * frame, without the staging copy in between (host/component.hpp).  One result may be waiting at a time: the next
+ * stage-by-stage call before the fetch fails with OATGPU_E_INVALID.  Results are those of the plain calls. */
+int oatgpu_set_deferred(oatgpu_ctx *ctx, int32_t on);
+int oatgpu_fetch_frame(oatgpu_ctx *ctx, uint8_t *frame_out);
+int oatgpu_fetch_position(oatgpu_ctx *ctx, oatgpu_position *out);
 
 /* ---- stage-by-stage operators (host buffers), one call == one reference call ---- */
 

@@ -108,6 +108,14 @@ struct oatgpu_ctx {
     std::vector<hipGraphExec_t> back_graph;           // [ring_slots], built lazily, dropped on set_detector
     int last_q = 0;
     std::string err;
+    // Deferred completion of the single-stage calls (oatgpu_set_deferred): the call returns when its INPUT has been read
+    // (the H2D copy is done), the result stays on the device until oatgpu_fetch_frame / oatgpu_fetch_position
+    bool deferred = false;
+    hipEvent_t ev_h2d = nullptr;
+    int defer_kind = 0;              // 0 nothing waiting, 1 a frame (defer_dev, defer_bytes), 2 a position (defer_s)
+    const uint8_t *defer_dev = nullptr;
+    size_t defer_bytes = 0;
+    int defer_s = 0;
     bool broken = false;             // a launch of the pipelined path failed half-way: the model and its rate schedule are ahead
                                      // of the results -- every later pipelined call is refused (oatgpu.h "Errors")
     // Temporal fusion (kernels_mog.hip "Two frames a launch"): with fuse == 2 a pipelined enqueue only REGISTERS its
@@ -363,6 +371,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->audit_dev);
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
     if (c->ev_c2) hipEventDestroy(c->ev_c2);
     for (auto e : c->copy_ev) hipEventDestroy(e);
     for (auto e : c->copy_ev_s) hipEventDestroy(e);
@@ -696,6 +705,7 @@ static int repair_outstanding(oatgpu_ctx *c);
 
 static int quiesce(oatgpu_ctx *c)
 {
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first (oatgpu_fetch_frame / oatgpu_fetch_position)");
     const int frc = flush_pending(c);
     if (frc) return frc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -725,6 +735,49 @@ static int check_stream_ix(oatgpu_ctx *c, int s)
     return OATGPU_OK;
 }
 
+// the input of a single-stage call on its way to the device; deferred: with an event behind it
+static int stage_in(oatgpu_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (c->deferred) {
+        if (!c->ev_h2d) HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming | hipEventDisableSystemFence));
+        HIPCHK(c, hipEventRecord(c->ev_h2d, c->stream));
+    }
+    return OATGPU_OK;
+}
+// the output frame of a single-stage call: copied out and waited for -- or, deferred, left on the device once the INPUT
+// has been read (FrameFilter.cpp:73-80: the reference posts its SOURCE right after its memcpy)
+static int finish_frame(oatgpu_ctx *c, uint8_t *out, const uint8_t *dev, size_t bytes)
+{
+    if (c->deferred) {
+        c->defer_kind = 1; c->defer_dev = dev; c->defer_bytes = bytes;
+        HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        return OATGPU_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_set_deferred(oatgpu_ctx *c, int32_t on)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first");
+    c->deferred = on != 0;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_fetch_frame(oatgpu_ctx *c, uint8_t *out)
+{
+    if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->defer_kind != 1) return fail(c, OATGPU_E_INVALID, "no deferred frame is waiting");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->defer_kind = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->defer_dev, c->defer_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OATGPU_OK;
+}
+
 static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask_out, uint8_t *bgr_out, double lr)
 {
     int rc = check_stream_ix(c, s);
@@ -736,7 +789,8 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     const size_t npx = (size_t)c->g.H * c->g.W;
     const size_t ch = c->cfg.channels;
     uint8_t *slot = c->frames + (size_t)s * npx * ch;
-    HIPCHK(c, hipMemcpyAsync(slot, bgr_in, npx * ch, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, slot, bgr_in, npx * ch);
+    if (rc) return rc;
     const Rate r = mog_begin(c, s, lr);
     MogLaunch a = mog_launch_base(c, c->frames, r);
     a.out_base = s;
@@ -744,6 +798,7 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     if (bgr_out) a.out_bgr = c->aux_b;
     launch_mog_fused(c->g, a, s, 1, c->stream);
     HIPCHK(c, hipGetLastError());
+    if (bgr_out && !mask_out) return finish_frame(c, bgr_out, c->aux_b, npx * ch);       // (deferrable: the filter form)
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, c->aux_a, npx, hipMemcpyDeviceToHost, c->stream));
     if (bgr_out) HIPCHK(c, hipMemcpyAsync(bgr_out, c->aux_b, npx * ch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -860,15 +915,14 @@ extern "C" int oatgpu_bsub_filter(oatgpu_ctx *c, int32_t s, const uint8_t *in, u
     }
     if (c->bsub_have[s] == 2 && alpha > 0.0)        // the reference's accumulateWeighted asserts on its empty fp32 image
         return fail(c, OATGPU_E_INVALID, "a background image from a file cannot adapt (adaptation-coeff must be 0)");
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, c->aux_a, in, nb);
+    if (rc) return rc;
     const float a = (float)alpha, b = 1 - a;              // accW_: AT a = (AT)alpha, b = 1 - a
     launch_bsub(c->aux_a, c->aux_b, c->bsub_bg + (size_t)s * nb, c->bsub_f + (size_t)s * nb, nb, a, b,
                 c->bsub_have[s] ? 0 : 1, alpha > 0.0 ? 1 : 0, c->stream);
     HIPCHK(c, hipGetLastError());
     if (!c->bsub_have[s]) c->bsub_have[s] = 1;
-    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OATGPU_OK;
+    return finish_frame(c, out, c->aux_b, nb);
 }
 
 extern "C" int oatgpu_bsub_set_background(oatgpu_ctx *c, int32_t s, const uint8_t *image)
@@ -900,15 +954,18 @@ extern "C" int oatgpu_mask_filter(oatgpu_ctx *c, int32_t s, const uint8_t *in, u
     if (rc) return rc;
     const size_t nb = (size_t)c->g.H * c->g.W * c->cfg.channels;
     if (!c->roi) {                                   // no mask set: FrameMasker::filter leaves the frame alone
+        if (c->deferred) {                           // (through the device, so that the fetch finds it)
+            rc = stage_in(c, c->aux_b, in, nb);
+            return rc ? rc : finish_frame(c, out, c->aux_b, nb);
+        }
         if (out != in) memcpy(out, in, nb);
         return OATGPU_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, c->aux_a, in, nb);
+    if (rc) return rc;
     launch_apply_roi(c->g, c->aux_a, c->aux_b, c->cfg.channels, c->roi + (size_t)s * (c->g.Palloc >> 6), c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OATGPU_OK;
+    return finish_frame(c, out, c->aux_b, nb);
 }
 
 extern "C" int oatgpu_thresh_filter(oatgpu_ctx *c, const uint8_t *in, uint8_t *out, int32_t i_min, int32_t i_max)
@@ -922,25 +979,23 @@ extern "C" int oatgpu_thresh_filter(oatgpu_ctx *c, const uint8_t *in, uint8_t *o
     const size_t npx = (size_t)c->g.H * c->g.W, nb = npx * c->cfg.channels;
     int lo, hi;
     norm_range(i_min, i_max, lo, hi);
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nb, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, c->aux_a, in, nb);
+    if (rc) return rc;
     launch_thresh_filter(c->aux_a, c->aux_b, npx, c->cfg.channels, lo, hi, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OATGPU_OK;
+    return finish_frame(c, out, c->aux_b, nb);
 }
 
 extern "C" int oatgpu_bgr2hsv(oatgpu_ctx *c, const uint8_t *bgr_in, uint8_t *hsv_out)
 {
     if (!c || !bgr_in || !hsv_out) return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first");
     const size_t npx = (size_t)c->g.H * c->g.W;
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, bgr_in, npx * 3, hipMemcpyHostToDevice, c->stream));
+    { const int rc = stage_in(c, c->aux_a, bgr_in, npx * 3); if (rc) return rc; }
     launch_bgr2hsv(c->aux_a, c->aux_b, npx, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hsv_out, c->aux_b, npx * 3, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OATGPU_OK;
+    return finish_frame(c, hsv_out, c->aux_b, npx * 3);
 }
 
 // ColorConvert::filter for any pair of oat::PixelColor values: oat::color_conv_table (Color.h:45-51) picks the
@@ -963,13 +1018,12 @@ extern "C" int oatgpu_cvt_color(oatgpu_ctx *c, int32_t from_color, int32_t to_co
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t npx = (size_t)c->g.H * c->g.W;
     const size_t nin = npx * (from_color >= 2 ? 3 : 1), nout = npx * (to_color >= 2 ? 3 : 1);
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, nin, hipMemcpyHostToDevice, c->stream));
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first");
+    { const int rc = stage_in(c, c->aux_a, in, nin); if (rc) return rc; }
     if (code == 3) launch_bgr2hsv(c->aux_a, c->aux_b, npx, c->stream);
     else launch_cvt_color(code, c->aux_a, c->aux_b, npx, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->aux_b, nout, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OATGPU_OK;
+    return finish_frame(c, out, c->aux_b, nout);
 }
 
 // contourMoments' epilogue (imgproc/moments.cpp) + siftContours' centroid
@@ -1030,19 +1084,25 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
 {
     int rc = check_stream_ix(c, s);
     if (rc) return rc;
-    if (!in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (!in || (!out && !c->deferred)) return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     rc = quiesce(c);
     if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W;
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, in, npx * channels, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, c->aux_a, in, npx * channels);
+    if (rc) return rc;
     RangeParams rp = range_of(c->cfg);
     launch_inrange_bits(g, c->aux_a, channels, rp, thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
     const int slot = c->ring_slots;       // the extra slot
     rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr);
     if (rc) return rc;
     c->last_q = 0;
+    if (c->deferred) {                    // the frame has been read; the position stays with the device (oatgpu_fetch_position)
+        c->defer_kind = 2; c->defer_s = s;
+        HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        return OATGPU_OK;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
     return OATGPU_OK;
@@ -1052,14 +1112,15 @@ extern "C" int oatgpu_detect_diff(oatgpu_ctx *c, int32_t s, const uint8_t *grey_
 {
     int rc = check_stream_ix(c, s);
     if (rc) return rc;
-    if (!grey_in || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (!grey_in || (!out && !c->deferred)) return fail(c, OATGPU_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     rc = quiesce(c);
     if (rc) return rc;
     const Geom &g = c->g;
     const size_t npx = (size_t)g.H * g.W;
     if (!c->diff_last) HIPCHK(c, hipMalloc((void **)&c->diff_last, (size_t)c->cfg.n_streams * npx));
-    HIPCHK(c, hipMemcpyAsync(c->aux_a, grey_in, npx, hipMemcpyHostToDevice, c->stream));
+    rc = stage_in(c, c->aux_a, grey_in, npx);
+    if (rc) return rc;
     const int have = c->diff_have[s];
     launch_absdiff_bits(g, c->aux_a, c->diff_last + (size_t)s * npx, c->cfg.diff_threshold, have,
                         thr_buf(c, 0) + (size_t)s * (g.Palloc >> 6), c->stream);
@@ -1069,6 +1130,11 @@ extern "C" int oatgpu_detect_diff(oatgpu_ctx *c, int32_t s, const uint8_t *grey_
     rc = back_half(c, c->bb[0], thr_buf(c, 0), s, 1, slot, c->stream, nullptr, 0, have ? c->cfg.blur : 0);
     if (rc) return rc;
     c->last_q = 0;
+    if (c->deferred) {
+        c->defer_kind = 2; c->defer_s = s;
+        HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        return OATGPU_OK;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     to_position(c->res_host[(size_t)slot * c->cfg.n_streams + s], out);
     return OATGPU_OK;
@@ -1081,6 +1147,17 @@ extern "C" int oatgpu_detect_hsv(oatgpu_ctx *c, int32_t s, const uint8_t *hsv_in
 extern "C" int oatgpu_detect_thresh(oatgpu_ctx *c, int32_t s, const uint8_t *grey_in, oatgpu_position *out)
 {
     return detect_single(c, s, grey_in, 1, out);
+}
+
+extern "C" int oatgpu_fetch_position(oatgpu_ctx *c, oatgpu_position *out)
+{
+    if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
+    if (c->defer_kind != 2) return fail(c, OATGPU_E_INVALID, "no deferred position is waiting");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->defer_kind = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    to_position(c->res_host[(size_t)c->ring_slots * c->cfg.n_streams + c->defer_s], out);
+    return OATGPU_OK;
 }
 
 // ------------------------------------------------------------ fused path ----

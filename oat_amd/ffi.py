@@ -88,6 +88,9 @@ SIGNATURES = {
     "oatgpu_bgr2hsv": (C.c_int, [_ctx, _u8p, _u8p]),
     "oatgpu_cvt_color": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8p, _u8p]),
     "oatgpu_set_fusion": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_set_deferred": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_fetch_frame": (C.c_int, [_ctx, _u8p]),
+    "oatgpu_fetch_position": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_set_early_blob": (C.c_int, [_ctx, C.c_int32]),
     "oatgpu_set_homography": (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_double)]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),

@@ -108,6 +108,10 @@ protected:
     virtual bool filter_from_shm(const Frame &, Frame &) { return false; }
     virtual PixelColor sink_color(PixelColor in) const { return in; }
     virtual void configure_for(const FrameParams &) {}
+    // The device context of a GPU filter whose filter_from_shm() may complete DEFERRED (oatgpu_set_deferred): process()
+    // then posts the SOURCE as soon as the frame has left shared memory and has the result copied straight into the SINK's
+    // shared frame (oatgpu_fetch_frame) -- no staging frame, no memcpy into the sink.  nullptr: the plain order below.
+    virtual oatgpu_ctx *deferred_ctx() { return nullptr; }
 
     // FrameFilter.cpp:37-57
     bool connectToNode() override
@@ -132,6 +136,27 @@ protected:
         const Frame &shm = *frame_source_.retrieve();
         src_pin_.pin(shm);
         const PixelColor out_color = shared_frame_.color();
+        if (oatgpu_ctx *dc = deferred_ctx()) {
+            // FrameFilter.cpp:59-98 with the GPU in the middle: the frame is DMA'd out of the source's segment (the read
+            // critical section ends there, as the reference's ends behind its memcpy), the kernels run while this
+            // component waits for its sink, and the result is DMA'd straight into the sink's segment inside the write
+            // critical section (where the reference memcpys).  One token out per token in, in order, with its Sample.
+            if (!deferred_on_) {
+                if (oatgpu_set_deferred(dc, 1) != OATGPU_OK) throw std::runtime_error(std::string("oatgpu: ") + oatgpu_last_error(dc));
+                deferred_on_ = true;
+            }
+            Frame nowhere(shm.rows(), shm.cols(), out_color, shared_frame_.data(), &deferred_sample_);   // (never written: deferred)
+            if (!filter_from_shm(shm, nowhere)) throw std::runtime_error("deferred filter refused the frame");
+            deferred_sample_ = shm.sample();
+            frame_source_.post();
+            frame_sink_.wait();
+            sink_pin_.pin(shared_frame_);
+            if (oatgpu_fetch_frame(dc, shared_frame_.data()) != OATGPU_OK)
+                throw std::runtime_error(std::string("oatgpu: ") + oatgpu_last_error(dc));
+            shared_frame_.sample() = deferred_sample_;
+            frame_sink_.post();
+            return 0;
+        }
         Frame &internal_frame = internal_.get(shm.rows(), shm.cols(), out_color);
         if (filter_from_shm(shm, internal_frame)) {
             internal_frame.sample() = shm.sample();
@@ -155,6 +180,9 @@ protected:
     Frame shared_frame_;
     PinnedFrame internal_;
     ShmRegistration src_pin_;      // declared after the source: unregistered before the segment is unmapped
+    ShmRegistration sink_pin_;     // ... and the sink's frame (the deferred path copies into it by DMA)
+    Sample deferred_sample_;
+    bool deferred_on_{false};
 };
 
 // src/positiondetector/PositionDetector.h:43-90
@@ -168,6 +196,9 @@ protected:
     virtual void detectPosition(Frame &frame, Position2D &position) = 0;   // PositionDetector.h:65
     // GPU fast path: detect straight out of the (registered) shared-memory frame, see FrameFilter.
     virtual bool detect_from_shm(const Frame &, Position2D &) { return false; }
+    // deferred detectors (oatgpu_set_deferred): detect_from_shm returned when the frame had been read; the position comes here,
+    // AFTER the source was posted
+    virtual void detect_finish(Position2D &) {}
     virtual void configure_for(const FrameParams &) {}
     PixelColor required_color_{PIX_BGR};
 
@@ -191,6 +222,7 @@ protected:
         internal_pos.set_sample(shm.sample());                 // PositionDetector.cpp:80
         if (detect_from_shm(shm, internal_pos)) {
             frame_source_.post();
+            detect_finish(internal_pos);
         } else {
             Frame internal_frame;
             frame_source_.copyTo(internal_frame);

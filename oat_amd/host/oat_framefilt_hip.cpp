@@ -45,6 +45,7 @@ protected:
         gpu_.check(oatgpu_mog_filter(gpu_.ctx, 0, in.data(), out.data(), learning_coeff_));
         return true;
     }
+    oatgpu_ctx *deferred_ctx() override { return gpu_.ctx; }
     GpuCtx gpu_;
 };
 
@@ -88,6 +89,7 @@ protected:
         out.set_color(color_);
         return true;
     }
+    oatgpu_ctx *deferred_ctx() override { return gpu_.ctx; }
     GpuCtx gpu_;
     PixelColor from_{PIX_BGR};
 };
@@ -129,6 +131,7 @@ protected:
         gpu_.check(oatgpu_bsub_filter(gpu_.ctx, 0, in.data(), out.data(), alpha_));
         return true;
     }
+    oatgpu_ctx *deferred_ctx() override { return gpu_.ctx; }
     GpuCtx gpu_;
 };
 
@@ -160,6 +163,7 @@ protected:
         gpu_.check(oatgpu_mask_filter(gpu_.ctx, 0, in.data(), out.data()));
         return true;
     }
+    oatgpu_ctx *deferred_ctx() override { return gpu_.ctx; }
     GpuCtx gpu_;
 };
 
@@ -187,6 +191,7 @@ protected:
         gpu_.check(oatgpu_thresh_filter(gpu_.ctx, in.data(), out.data(), i_min_, i_max_));
         return true;
     }
+    oatgpu_ctx *deferred_ctx() override { return gpu_.ctx; }
     GpuCtx gpu_;
 };
 

@@ -28,10 +28,22 @@ protected:
         gpu_.create(cfg_);
     }
     // HSVDetector.cpp:142-173 / SimpleThreshold.cpp:114-134
-    bool detect_from_shm(const Frame &frame, Position2D &position) override
+    // Deferred (oatgpu_set_deferred): the call returns when the frame has left shared memory, PositionDetector::process posts
+    // the source, and detect_finish() waits for the kernels and takes the position (PositionDetector.cpp:78-96).
+    bool detect_from_shm(const Frame &frame, Position2D &) override
     {
-        detectPosition(const_cast<Frame &>(frame), position);      // reads only
+        if (!deferred_on_) { gpu_.check(oatgpu_set_deferred(gpu_.ctx, 1)); deferred_on_ = true; }
+        gpu_.check(kind_ == Kind::HSV ? oatgpu_detect_hsv(gpu_.ctx, 0, frame.data(), nullptr)
+                   : kind_ == Kind::THRESH ? oatgpu_detect_thresh(gpu_.ctx, 0, frame.data(), nullptr)
+                                           : oatgpu_detect_diff(gpu_.ctx, 0, frame.data(), nullptr));
         return true;
+    }
+    void detect_finish(Position2D &position) override
+    {
+        oatgpu_position r;
+        gpu_.check(oatgpu_fetch_position(gpu_.ctx, &r));
+        position.position_valid = r.valid != 0;                   // DetectorFunc.cpp:46,58-60
+        if (r.valid) { position.position.x = r.x; position.position.y = r.y; }
     }
     void detectPosition(Frame &frame, Position2D &position) override
     {
@@ -43,6 +55,7 @@ protected:
         if (r.valid) { position.position.x = r.x; position.position.y = r.y; }
     }
     Kind kind_;
+    bool deferred_on_{false};
     GpuCtx gpu_;
 };
 

@@ -1197,6 +1197,60 @@ def test_stage_camera_by_camera_equals_enqueue(A, stage_copy):
     hp.collect(); hp.collect()
 
 
+def test_deferred_single_stage_calls_equal_the_plain_ones(A):
+    """oatgpu_set_deferred (ABI 7): a frame filter / detector returns when its input has been read and keeps its result on the
+    device; oatgpu_fetch_frame / oatgpu_fetch_position deliver what the plain call would have written -- mog (the model
+    advances exactly once per call), bsub, thresh, cvt_color, detect_hsv.  The caller's input buffer may be scribbled on
+    as soon as the call has returned; a second call before the fetch is refused; a fetch with nothing waiting too."""
+    import ctypes as C
+    from oat_amd import ffi
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    rows, cols = 120, 200
+    st = SyntheticStream(rows, cols, 7, n_discs=2, radius=10)
+    frames = [st.frame(t, with_discs=t > 0) for t in range(6)]
+    kw = dict(erode=2, dilate=4, area=(5.0, 1e5), **disc_hsv_window())
+    plain, dfr = A.HotPath(rows, cols, adaptation_coeff=0.02, **kw), A.HotPath(rows, cols, adaptation_coeff=0.02, **kw)
+    lib = dfr.lib
+    assert lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(np.empty((rows, cols, 3), np.uint8))) < 0       # nothing waiting
+    ffi.check(lib, dfr.ctx, lib.oatgpu_set_deferred(dfr.ctx, 1))
+    for t, f in enumerate(frames):
+        want = np.empty_like(f)
+        ffi.check(lib, plain.ctx, lib.oatgpu_mog_filter(plain.ctx, 0, ffi.u8(f), ffi.u8(want), 0.02))
+        buf, got = f.copy(), np.full_like(f, 99)
+        ffi.check(lib, dfr.ctx, lib.oatgpu_mog_filter(dfr.ctx, 0, ffi.u8(buf), ffi.u8(got), 0.02))
+        assert (got == 99).all()                                     # deferred: the output argument is not written
+        buf[...] = 7                                                 # the input has been read: scribble
+        assert lib.oatgpu_mog_filter(dfr.ctx, 0, ffi.u8(f), ffi.u8(got), 0.02) < 0           # one result at a time
+        assert lib.oatgpu_fetch_position(dfr.ctx, C.byref(ffi.Position())) < 0              # ... and of the right kind
+        ffi.check(lib, dfr.ctx, lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(got)))
+        assert (got == want).all(), t
+        # the filtered frame through col -C HSV and posidet hsv, both deferred
+        hsv_w, hsv_g = np.empty_like(f), np.empty_like(f)
+        ffi.check(lib, plain.ctx, lib.oatgpu_cvt_color(plain.ctx, 2, 3, ffi.u8(want), ffi.u8(hsv_w)))
+        ffi.check(lib, dfr.ctx, lib.oatgpu_cvt_color(dfr.ctx, 2, 3, ffi.u8(got), ffi.u8(hsv_g)))
+        ffi.check(lib, dfr.ctx, lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(hsv_g)))
+        assert (hsv_g == hsv_w).all(), t
+        pw, pg = ffi.Position(), ffi.Position()
+        ffi.check(lib, plain.ctx, lib.oatgpu_detect_hsv(plain.ctx, 0, ffi.u8(hsv_w), C.byref(pw)))
+        ffi.check(lib, dfr.ctx, lib.oatgpu_detect_hsv(dfr.ctx, 0, ffi.u8(hsv_g), None))
+        assert lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(got)) < 0
+        ffi.check(lib, dfr.ctx, lib.oatgpu_fetch_position(dfr.ctx, C.byref(pg)))
+        assert (pg.valid, pg.a00, pg.a10, pg.a01, pg.x, pg.y) == (pw.valid, pw.a00, pw.a10, pw.a01, pw.x, pw.y), t
+    assert (plain.mog_state()[1] == dfr.mog_state()[1]).all()                               # same model on both sides
+    # bsub and thresh the same way
+    for name, args in (("oatgpu_bsub_filter", lambda c, i, o: (c, 0, i, o, 0.05)), ("oatgpu_thresh_filter", lambda c, i, o: (c, i, o, 100, 200))):
+        for f in frames[:3]:
+            want, got = np.empty_like(f), np.empty_like(f)
+            ffi.check(lib, plain.ctx, getattr(lib, name)(*args(plain.ctx, ffi.u8(f), ffi.u8(want))))
+            ffi.check(lib, dfr.ctx, getattr(lib, name)(*args(dfr.ctx, ffi.u8(f), ffi.u8(got))))
+            ffi.check(lib, dfr.ctx, lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(got)))
+            assert (got == want).all(), name
+    ffi.check(lib, dfr.ctx, lib.oatgpu_set_deferred(dfr.ctx, 0))
+    got = np.empty_like(frames[0])
+    ffi.check(lib, dfr.ctx, lib.oatgpu_thresh_filter(dfr.ctx, ffi.u8(frames[0]), ffi.u8(got), 100, 200))    # plain again
+    assert lib.oatgpu_fetch_frame(dfr.ctx, ffi.u8(got)) < 0
+
+
 def test_stage_abort_gives_up_a_partly_staged_set(A):
     """oatgpu_track_stage_abort (ABI 7): a camera ended in the middle of a round.  The set is forgotten --
     no result is owed, the model has not moved -- and the context goes on: the next complete set gives what a context
