@@ -183,15 +183,14 @@ int oatgpu_synchronize(oatgpu_ctx *ctx);
 int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
 /* Early dispatch of the blob-analysis workgroup (default OFF; a latency / throughput trade for saturated pipelines).  With
- * on = 1, on the pipelined device-frame path of steps of 4 MP and more, the single big workgroup that labels a frame's
- * mask (findContours + moments, DetectorFunc.cpp:41-63) is submitted on a HIP stream of its own together with the frame's
- * other kernels and WAITS ON THE DEVICE for the frame's row scan: it takes its wave slots while the per-pixel kernel of an
- * earlier frame drains instead of queueing for them on the frame's critical path (4K: row scan + blob analysis 113 -> 62 us
- * beside the per-pixel kernel).  The parked workgroup costs the per-pixel kernel more than its 16 wave slots: 4 % of the
- * frame rate with one of them (one 4K stream), ~18 % with 32 (16 x 1080p, two frames in flight) -- hence opt-in.
- * Results are identical either way.  Keep it off under tools that serialise kernel dispatches -- a counter-collecting
- * profiler (rocprofv3 --pmc) would let the waiting workgroup run before the row scan it waits for; the kernel then gives
- * up after 100 ms and the frame is redone by the global kernels: correct, but slow. */
+ * on = 1, on the pipelined device-frame path of steps of 4 MP and more, the big workgroups that label a step's masks
+ * (findContours + moments, DetectorFunc.cpp:41-63) are submitted on a HIP stream of their own together with the step's other
+ * kernels and WAIT ON THE DEVICE for their frames' row scans: they take their wave slots while the per-pixel kernel of an
+ * earlier frame drains instead of queueing for them on the frame's critical path (row scan + blob analysis beside the
+ * per-pixel kernel: 4K 117 -> 64 us, 16 x 1080p 427 -> 69 us) for 1-3 % of the frame rate.  Results are identical either way.
+ * Keep it off under tools that serialise kernel dispatches -- a counter-collecting profiler (rocprofv3 --pmc) would let
+ * the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is
+ * redone by the global kernels: correct, but slow. */
 int oatgpu_set_early_blob(oatgpu_ctx *ctx, int32_t on);
 
 /* Re-configure the detector between frames (what the reference's tuning GUI

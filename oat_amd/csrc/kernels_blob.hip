@@ -162,18 +162,9 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // dilation (dil_k > 1) on the fly, writes the final mask (image frame zeroed,
 // as cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start
 // x of the run entering every word, and initialises the union-find at run heads.
-// SIGNAL (r04, "Early dispatch" below): what k_blob_lds reads of this kernel's output -- fin, trans, wpre, rowinfo -- is
-// stored with agent-scope atomic stores (write-through: visible to a workgroup that is already running on another XCD,
-// whose L2 is not coherent with this one's for plain stores), and the LAST workgroup of a stream to arrive publishes
-// `ticket` in b.ready[s]: the frame's row scan is complete.
-template <typename T> __device__ __forceinline__ void st_pub(T *p, T v, bool signal)
-{
-    if (signal) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool ERODE, bool SIGNAL = false>
+template <bool ERODE>
 __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                 int first_stream, int clear_lds_ok, unsigned ticket = 0u)
+                                                 int first_stream, int clear_lds_ok)
 {
     extern __shared__ u64 er[];
     const int lane = threadIdx.x & 63;
@@ -202,7 +193,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
         }
         __syncthreads();
     }
-    if (y < g.H) {
+    if (y >= g.H) return;
     const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     u64 *morph = b.morph + woff;
     u64 *fin = b.fin + woff;
@@ -263,10 +254,10 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             if (lane >= o) incl += v;
         }
         if (active) {
-            st_pub(fin + w, F, SIGNAL);
-            st_pub(trans + w, T, SIGNAL);
+            fin[w] = F;
+            trans[w] = T;
             carry[w] = cin;
-            st_pub(wpre + w, (unsigned short)min(runs_before + incl - cntT, 65535u), SIGNAL);
+            wpre[w] = (unsigned short)min(runs_before + incl - cntT, 65535u);
         }
         keepT = T; keepF = F;
         runs_before += __shfl(incl, 63);
@@ -285,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     // belong to the OUTSIDE component: hang them under root 0 right away -- on ordinary frames
     // this removes the H-long merge chain of full-width background runs.  Foreground run heads
     // get their Green accumulators cleared here.
-    if (lane == 0) st_pub(b.rowinfo + (size_t)s * g.H + y, row_fg ? (int)runs_before : 0, SIGNAL);
+    if (lane == 0) b.rowinfo[(size_t)s * g.H + y] = row_fg ? (int)runs_before : 0;
     const int last_start = chunk_carry;          // start x of the row's last run
     long long *acc = b.acc + (size_t)s * g.Palloc * 3;
     for (int c0 = 0; c0 < g.words; c0 += 64) {
@@ -302,21 +293,6 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             const int head = y * g.Wp + sx;
             parent[head] = (sx == 0 || sx == last_start) ? 0 : head;
             if ((F >> i) & 1ull) { acc[(size_t)head * 3] = 0; acc[(size_t)head * 3 + 1] = 0; acc[(size_t)head * 3 + 2] = 0; }
-        }
-    }
-    }       // y < g.H
-    if (SIGNAL) {
-        // every store of this workgroup has been acknowledged (the published arrays were written through), then ONE
-        // arrival per workgroup; the last arriver of the stream re-arms the counter and publishes the ticket
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(&b.rs_done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == gridDim.x - 1) {
-                __hip_atomic_store(&b.rs_done[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (relaxed: no cache maintenance -- every published store above was written through and acknowledged)
-                __hip_atomic_store(&b.ready[s], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }
@@ -715,10 +691,17 @@ template <typename T> __device__ __forceinline__ T ld_pub(const T *p)
 {
     return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b, double min_area, double max_area,
-                                                        ResultRec *results, int first_stream, int spec, unsigned wait_ticket)
+// blockIdx.z selects one of TWO frames (scratch set, result record, ticket): the two frames of a two-frame step park
+// their workgroups with ONE launch (launch_blob_tail2) -- two launches on one stream would run one after the other.
+__global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, BlobBuffers b1, double min_area, double max_area,
+                                                        ResultRec *results0, ResultRec *results1, int first_stream, int spec,
+                                                        unsigned ticket0, unsigned ticket1)
 {
     __shared__ int wait_failed;
+    const bool second = blockIdx.z != 0;
+    const BlobBuffers &b = second ? b1 : b0;
+    ResultRec *const results = second ? results1 : results0;
+    const unsigned wait_ticket = second ? ticket1 : ticket0;
     __shared__ unsigned short rows[kLdsRows + 1];        // dirty row r -> image row
     __shared__ unsigned rptr[kLdsRows + 2];              // dirty row r -> its first node
     __shared__ unsigned short rstart[kLdsRuns + 2];      // node -> start x
@@ -1125,8 +1108,8 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
         hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
                            dil_k, b, first_stream, clear);
     if (lds_able && mode != kBlobGlobal)
-        hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, min_area, max_area, results,
-                           first_stream, mode == kBlobSpec ? 1 : 0, 0u);
+        hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, b, min_area, max_area, results, results,
+                           first_stream, mode == kBlobSpec ? 1 : 0, 0u, 0u);
     if (mode == kBlobSpec) return;
     if (g.H > 1)
         hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
@@ -1137,31 +1120,36 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
                        min_area, max_area, results, first_stream);
 }
 
+// The frame's ticket comes from a kernel of its own behind the row scan: the stream's order and the row scan's
+// end-of-kernel release make its output visible to agent-scope loads, one lane per stream publishes.  (The in-kernel
+// form -- k_rowscan storing what k_blob_lds reads write-through and its last-arriving workgroup publishing the ticket --
+// saved that launch and cost the per-pixel kernel 3-4 %: profiles/r04o_*, r04p_*.)
+__global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned ticket)
+{
+    __hip_atomic_store(&ready[first_stream + threadIdx.x], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
                            int n_streams, unsigned ticket, hipStream_t st)
 {
     if (ero_k > 1)
-        hipLaunchKernelGGL((k_rowscan<true, true>), dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
-                           st, g, src_bits, ero_k, dil_k, b, first_stream, 0, ticket);
+        hipLaunchKernelGGL(k_rowscan<true>, dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
+                           st, g, src_bits, ero_k, dil_k, b, first_stream, 0);
     else
-        hipLaunchKernelGGL((k_rowscan<false, true>), dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
-                           dil_k, b, first_stream, 0, ticket);
+        hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
+                           dil_k, b, first_stream, 0);
+    for (int s0 = 0; s0 < n_streams; s0 += 1024)
+        hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
+                           first_stream + s0, ticket);
 }
 
-void launch_blob_tail(const Geom &g, const BlobBuffers &b, double min_area, double max_area, ResultRec *results,
-                      int first_stream, int n_streams, unsigned ticket, int mode, hipEvent_t rowscan_done, hipStream_t st)
+// The early blob workgroups of the nf (1 or 2) frames of a step in ONE launch: frame i reads scratch set b[i], writes
+// results[i] and waits for ticket[i].  Speculative mode only (a declined frame comes back marked kNeedsGlobal).
+void launch_blob_tail2(const Geom &g, const BlobBuffers *b, double min_area, double max_area, ResultRec *const *results,
+                       int n_streams, const unsigned *ticket, int nf, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, min_area, max_area, results,
-                       first_stream, mode == kBlobSpec ? 1 : 0, ticket);
-    if (mode == kBlobSpec) return;
-    // the global kernels read what the row scan stored PLAINLY (parent, carry, the accumulators): behind its kernel boundary
-    if (rowscan_done) (void)hipStreamWaitEvent(st, rowscan_done, 0);
-    if (g.H > 1)
-        hipLaunchKernelGGL(k_merge, dim3(((g.H - 1) * g.words + 255) / 256, n_streams), dim3(256), 0, st, g, b,
-                           first_stream);
-    const int nw = (g.H > 2 ? (g.H - 2) * g.words : 1) * kGreenChunks;
-    hipLaunchKernelGGL(k_green_select, dim3((nw + kGreenBlock - 1) / kGreenBlock, n_streams), dim3(kGreenBlock), 0, st, g, b,
-                       min_area, max_area, results, first_stream);
+    const int k = nf > 1 ? 1 : 0;
+    hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams, nf), dim3(kLdsBlock), 0, st, g, b[0], b[k], min_area, max_area, results[0],
+                       results[k], 0, 1, ticket[0], ticket[k]);
 }
 
 }  // namespace oatgpu

@@ -86,13 +86,13 @@ struct oatgpu_ctx {
     bool kal_on = false;
     unsigned kal_ticket = 0;         // ticket of the next enqueued frame
     int expt = 0;
-    // Early dispatch of the blob workgroup (kernels_blob.hip): the back half of a device-frame step goes down TWO streams --
-    // every row scan on B0, everything behind it on B1 / B2 by frame parity, whose k_blob_lds is submitted with the
-    // step and waits on the device for its row scan's ticket.  Scratch sets 0 / 1 by frame parity; repairs of declined
-    // frames use set 2 on B0.
+    // Early dispatch of the blob workgroup (kernels_blob.hip): the row scans of a device-frame step go down B0 / B1 by frame
+    // parity, as on the plain path; the k_blob_lds workgroups of the step's frames are submitted with them as ONE launch on
+    // B2 and wait on the device for their row scans' tickets.  Scratch sets 0 / 1 by frame parity; repairs of declined
+    // frames use set 2 on B2.
     bool early_blob = false;         // opt-in (oatgpu_set_early_blob): it shortens a saturated pipeline's back half by ~50 us and
                                      // costs the per-pixel kernel 4 % (one parked workgroup at 4K) to 20 % (32 of them, 16 x 1080p)
-    bool early_nopark = false;       // measurement: the early path's stream layout WITHOUT the parked workgroup (blob behind an event)
+       // measurement: the early path's stream layout WITHOUT the parked workgroup (blob behind an event)
     bool stage_kernel = false;       // oatgpu_set_stage_copy(1): oatgpu_track_stage copies with a kernel reading the host frame in place
     int k1_stop_event = -1;          // the step's "K1 done" event rides on the last K1 launch's own completion signal (no marker
                                      // packet behind it on stream A): -1 by step size (>= 4 MP: +1..2.5 % at 4K; small steps are
@@ -100,7 +100,7 @@ struct oatgpu_ctx {
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
-    hipEvent_t ev_blob[kNB] = {}, ev_rs[kNB] = {};   // scratch set q: its latest reader is done / its latest row scan is done
+    hipEvent_t ev_blob[kNB] = {};    // scratch set q: its latest reader is done
     bool ev_blob_valid[kNB] = {};
     std::vector<char> slot_st;       // per ring slot: B stream its result event was recorded on / its repair goes to
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
@@ -379,14 +379,13 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
         hipFree(b.roots); hipFree(b.nroots); hipFree(b.wpre); hipFree(b.rowinfo); hipFree(b.lds_ok);
-        hipFree(b.ready); hipFree(b.rs_done);
+        hipFree(b.ready);
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
     for (int q = 0; q < oatgpu_ctx::kNB; ++q) {
         if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
         if (c->ev_blob[q]) hipEventDestroy(c->ev_blob[q]);
-        if (c->ev_rs[q]) hipEventDestroy(c->ev_rs[q]);
     }
     for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto e : c->ring_ev) hipEventDestroy(e);
@@ -479,10 +478,10 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     for (int q = 0; q < c->nb && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;
         if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
-        if (ok) ok = hipEventCreateWithFlags(&c->ev_rs[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e) != 0;
-    if (const char *e = measure_env("OATGPU_EARLY_NOPARK")) c->early_nopark = atoi(e) != 0;
+
+
     if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0 ? 1 : 0;
 
     A((void **)&c->state, n * mog_stream_floats(g.Palloc) * sizeof(float));
@@ -510,7 +509,6 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
         A((void **)&b.lds_ok, n * sizeof(unsigned));
         A((void **)&b.ready, n * sizeof(unsigned));
-        A((void **)&b.rs_done, n * sizeof(unsigned));
     }
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
@@ -542,7 +540,6 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.lds_ok, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
         if (ok && hipMemsetAsync(b.ready, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
-        if (ok && hipMemsetAsync(b.rs_done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
@@ -1441,59 +1438,61 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // per-pixel launches are short, the wait for wave slots with them, and the step is bound by the host's launch calls,
     // of which this path makes two more: one 1080p stream 50 k -> 37 k fps), three B streams, a frame geometry the LDS
     // kernel takes
-    const bool early = c->early_blob && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
+    // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
+    // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
+    const bool early = c->early_blob && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
                        c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
     if (c->last_early >= 0 && c->last_early != (int)early)          // the two paths use the scratch sets from different streams
         for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     c->last_early = (int)early;
-    for (int i = 0; i < nj && early; ++i) {
-        const int slot = j[i].slot, q = slot & 1;
-        hipStream_t R = c->stream_b[0], C = c->stream_b[1 + q];
-        c->b_used[0] = c->b_used[1 + q] = true;
-        ProfStep *pb = i == 0 ? ps : nullptr;
-        BlobBuffers &bb = c->bb[q];
-        // ---- B0: the row scan, behind this step's per-pixel kernel and behind the last reader of scratch set q ----
-        if (i == 0) HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
-        if (c->ev_blob_valid[q]) HIPCHK(c, hipStreamWaitEvent(R, c->ev_blob[q], 0));
-        if (pb) HIPCHK(c, hipEventRecord(pb->e[2], R));
+    if (early) {
         const Geom &g = c->g;
-        const u64 *src = thr_buf(c, slot);
-        const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-        int ero = c->cfg.erode > 1 ? c->cfg.erode : 0;
-        if (ero && rowscan_lds_bytes(g, dil) > kRowscanLdsMax) {     // very wide rows x large dilation
-            launch_morph(g, src, bb.tmp, ero, true, 0, n, R);
-            src = bb.tmp;
-            ero = 0;
+        hipStream_t C = c->stream_b[2];
+        c->b_used[0] = c->b_used[1] = c->b_used[2] = true;
+        BlobBuffers bbs[2];
+        ResultRec *res[2];
+        unsigned tk[2] = {0, 0};
+        for (int i = 0; i < nj; ++i) {
+            const int slot = j[i].slot, q = slot & 1;
+            hipStream_t R = c->stream_b[q];
+            ProfStep *pb = i == 0 ? ps : nullptr;
+            BlobBuffers &bb = c->bb[q];
+            // ---- B0 / B1: the frame's row scan, behind the step's per-pixel kernel and the last reader of scratch set q ----
+            HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
+            if (c->ev_blob_valid[q]) HIPCHK(c, hipStreamWaitEvent(R, c->ev_blob[q], 0));
+            if (pb) HIPCHK(c, hipEventRecord(pb->e[2], R));
+            const u64 *src = thr_buf(c, slot);
+            const int dil = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+            int ero = c->cfg.erode > 1 ? c->cfg.erode : 0;
+            if (ero && rowscan_lds_bytes(g, dil) > kRowscanLdsMax) {     // very wide rows x large dilation
+                launch_morph(g, src, bb.tmp, ero, true, 0, n, R);
+                src = bb.tmp;
+                ero = 0;
+            }
+            if (pb) HIPCHK(c, hipEventRecord(pb->e[3], R));
+            c->last_morph = (dil || ero) ? bb.morph : src;
+            c->last_fin = bb.fin;
+            unsigned ticket = ++c->bh_ticket[q];
+            if (!ticket) ticket = ++c->bh_ticket[q];
+            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
+            bbs[i] = bb; res[i] = c->res_dev + (size_t)slot * n; tk[i] = ticket;
+            c->slot_spec[slot] = 1;
+            c->slot_q[slot] = 2;                         // a repair redoes the frame in scratch set 2 ...
+            c->slot_st[slot] = 2;                        // ... on B2, behind the blob launches
+            c->slot_filtered[slot] = 0;
         }
-        if (pb) HIPCHK(c, hipEventRecord(pb->e[3], R));
-        c->last_morph = (dil || ero) ? bb.morph : src;
-        c->last_fin = bb.fin;
-        unsigned ticket = ++c->bh_ticket[q];
-        if (!ticket) ticket = ++c->bh_ticket[q];
-        launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
-        const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;
-        if (mode == kBlobFull || c->early_nopark) HIPCHK(c, hipEventRecord(c->ev_rs[q], R));
-        if (c->early_nopark) { HIPCHK(c, hipStreamWaitEvent(C, c->ev_rs[q], 0)); ticket = 0; }
-        // ---- B1 / B2: the blob workgroup, dispatched now, started by the row scan's ticket; then whatever follows ----
-        launch_blob_tail(g, bb, c->cfg.min_area, c->cfg.max_area, c->res_dev + (size_t)slot * n, 0, n, ticket, mode,
-                         mode == kBlobFull ? c->ev_rs[q] : nullptr, C);
+        // ---- B2: the blob workgroups of the step's frames, ONE launch, dispatched now, started by their row scans' tickets ----
+        launch_blob_tail2(g, bbs, c->cfg.min_area, c->cfg.max_area, res, n, tk, nj, C);
         HIPCHK(c, hipGetLastError());
-        c->slot_spec[slot] = mode == kBlobSpec;
-        c->slot_q[slot] = 2;                             // a repair redoes the frame in scratch set 2 ...
-        c->slot_st[slot] = 0;                            // ... on B0, in line with the row scans
-        if (c->kal_on) {
-            KalmanLaunch kl = c->kal;
-            kl.ticket = c->kal_ticket++;
-            launch_kalman(kl, c->res_dev + (size_t)slot * n, n, C);
-            HIPCHK(c, hipGetLastError());
+        if (ps) HIPCHK(c, hipEventRecord(ps->e[4], C));
+        for (int i = 0; i < nj; ++i) {
+            const int slot = j[i].slot, q = slot & 1;
+            c->slot_ev[slot] = j[nj - 1].slot;           // one ring event behind the step's blob launch covers both results
+            HIPCHK(c, hipEventRecord(c->ev_blob[q], C));
+            c->ev_blob_valid[q] = true;
+            c->last_q = slot;
         }
-        c->slot_filtered[slot] = c->kal_on;
-        if (pb) HIPCHK(c, hipEventRecord(pb->e[4], C));
-        c->slot_ev[slot] = slot;
-        HIPCHK(c, hipEventRecord(c->ring_ev[slot], C));
-        HIPCHK(c, hipEventRecord(c->ev_blob[q], C));
-        c->ev_blob_valid[q] = true;
-        c->last_q = slot;
+        HIPCHK(c, hipEventRecord(c->ring_ev[j[nj - 1].slot], C));
     }
     for (int i = 0; i < nj && !early; ++i) {
         const int slot = j[i].slot;

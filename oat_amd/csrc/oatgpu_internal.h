@@ -159,10 +159,9 @@ struct BlobBuffers {
     unsigned short *wpre;  // [n][H*words] run starts of the row in the words before this one
     int *rowinfo;          // [n][H]       0: no foreground in the row; else its number of runs
     unsigned *lds_ok;      // [n]          1: k_blob_lds wrote this frame's result, k_merge / k_green_select stand down
-    // the early blob workgroup (kernels_blob.hip "Early dispatch"): k_rowscan's last workgroup of a stream publishes the
-    // frame's ticket, the k_blob_lds workgroup that was dispatched ahead of it waits for exactly that ticket
-    unsigned *ready;       // [n]          ticket of the latest frame whose row scan is complete
-    unsigned *rs_done;     // [n]          arrival counter of k_rowscan's workgroups
+    // the early blob workgroup (kernels_blob.hip "Early dispatch"): a one-lane kernel behind the row scan publishes the frame's
+    // ticket, the k_blob_lds workgroup that was dispatched ahead of it waits for exactly that ticket
+    unsigned *ready;       // [n]          ticket of the latest frame whose row scan is complete (k_publish_ticket)
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -208,13 +207,14 @@ enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
 constexpr int kNeedsGlobal = -2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
-// The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan, which publishes `ticket`
-// when its last workgroup is through, and everything behind it, whose k_blob_lds workgroup may be dispatched long before
-// the row scan has run and waits for `ticket` on the device.  ticket != 0.  The caller orders st_tail behind the row
-// scan with an event before launch_blob_tail's global kernels may run (mode kBlobFull: pass that event, else nullptr).
+// The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan with a one-lane kernel behind
+// it that publishes `ticket`, and everything behind the row scan, whose k_blob_lds workgroup may be dispatched long before
+// the row scan has run and waits for `ticket` on the device.  ticket != 0.
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
                            int n_streams, unsigned ticket, hipStream_t st);
-void launch_blob_tail(const Geom &g, const BlobBuffers &b, double min_area, double max_area, ResultRec *results,
-                      int first_stream, int n_streams, unsigned ticket, int mode, hipEvent_t rowscan_done, hipStream_t st_tail);
+// the blob workgroups of the nf (1 or 2) frames of a step in ONE launch (speculative mode): arrays of nf scratch sets,
+// result records and tickets
+void launch_blob_tail2(const Geom &g, const BlobBuffers *b, double min_area, double max_area, ResultRec *const *results,
+                       int n_streams, const unsigned *ticket, int nf, hipStream_t st_tail);
 
 }  // namespace oatgpu
