@@ -100,6 +100,7 @@ struct oatgpu_ctx {
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
+    unsigned early_frames = 0;       // frames that took the early path (their parity picks scratch set and row-scan stream)
     hipEvent_t ev_blob[kNB] = {};    // scratch set q: its latest reader is done
     bool ev_blob_valid[kNB] = {};
     std::vector<char> slot_st;       // per ring slot: B stream its result event was recorded on / its repair goes to
@@ -1452,8 +1453,12 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         BlobBuffers bbs[2];
         ResultRec *res[2];
         unsigned tk[2] = {0, 0};
+        int qs[2] = {0, 0};
         for (int i = 0; i < nj; ++i) {
-            const int slot = j[i].slot, q = slot & 1;
+            // scratch set / row-scan stream by FRAME parity (not by ring slot: with an odd ring depth two consecutive frames
+            // can sit in slots of the same parity, and the two frames of a step must not share a scratch set)
+            const int slot = j[i].slot, q = (int)(c->early_frames++ & 1u);
+            qs[i] = q;
             hipStream_t R = c->stream_b[q];
             ProfStep *pb = i == 0 ? ps : nullptr;
             BlobBuffers &bb = c->bb[q];
@@ -1486,7 +1491,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         HIPCHK(c, hipGetLastError());
         if (ps) HIPCHK(c, hipEventRecord(ps->e[4], C));
         for (int i = 0; i < nj; ++i) {
-            const int slot = j[i].slot, q = slot & 1;
+            const int slot = j[i].slot, q = qs[i];
             c->slot_ev[slot] = j[nj - 1].slot;           // one ring event behind the step's blob launch covers both results
             HIPCHK(c, hipEventRecord(c->ev_blob[q], C));
             c->ev_blob_valid[q] = true;

@@ -1321,14 +1321,16 @@ def test_back_half_speculation_and_repair(A):
             _same_detection(got[t][s], want, (t, s, pattern[t]))
 
 
-@pytest.mark.parametrize("fusion,ring,kalman", [(2, 4, False), (1, 2, False), (2, 3, True)])
+@pytest.mark.parametrize("fusion,ring,kalman", [(2, 4, False), (1, 2, False), (2, 3, True), (2, 3, False), (2, 5, False), (1, 3, False)])
 def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
     """Early dispatch of the blob workgroup (r04; oatgpu_set_early_blob, kernels_blob.hip): on the pipelined device-frame path
     the k_blob_lds workgroup of a frame is submitted on its own stream ahead of the frame's row scan and waits on the
     device for the row scan's ticket.  Frames big enough to take that path (>= 4 MP a step), quiet and BUSY ones in every
     pattern a ring can see (busy = declined by the LDS kernel -> repaired by the global kernels in scratch set 2; then the
-    full launch sequence until the streak is back), with and without two frames a launch and with the position filter
-    (never speculative): every result equals the plain path's and the oracle's, the threshold masks too."""
+    full launch sequence until the streak is back), with and without two frames a launch, with ODD ring depths (two
+    consecutive frames then sit in ring slots of the same parity -- the scratch sets go by frame parity) and with the
+    position filter (never speculative: the plain order): every result equals the plain path's and the oracle's, the
+    threshold masks too."""
     import torch
     rows, cols, n = 1080, 1920, 2                                   # 2 x 2.07 MP = 4.15 MP a step
     rng = np.random.default_rng(31 + fusion + ring)
