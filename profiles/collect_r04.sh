@@ -46,7 +46,7 @@ cd $R
 bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_sparse --workload 4k1 --steps 40 --warmup 100 > /dev/null 2>&1
 bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_dense --workload 4k1 --dense-model --steps 40 --warmup 20 > /dev/null 2>&1
 bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_sparse_one_frame --workload 4k1 --steps 40 --warmup 100 --fusion 1 > /dev/null 2>&1
-for m in dma kernel; do
+for m in dma; do
   echo "== --stage-copy $m"
   timeout 300 python tools/pipeline_fps.py --rows 1080 --cols 1920 --frames 6000 --fused --cameras 8 --ring 4 --stage-copy $m --timing 2>&1 | grep -v Exiting | tail -3
 done > $O/${TAG}_pipeline_8cam_timing.txt
