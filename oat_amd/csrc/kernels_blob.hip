@@ -954,7 +954,32 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
 #ifdef OATGPU_LDS_TIMING
         if (i0 == (unsigned)(t >> lpr_log)) { TK(); }
 #endif
+        // state of a neighbour row over [x0 - 1, x0 + 64] from the run list: 1 all foreground, 0 all OUTSIDE background,
+        // 2 all background of a hole, -1 mixed (or the word is at the frame's edge)
+        auto row_state = [&](Memo &m, unsigned rr, bool adj, int x0) -> int {
+            if (!adj) return 0;                                       // the row is not in the list: no foreground, all outside
+            const int rt = root_at(m, rr, x0);
+            if (m.lo > x0 - 1 || m.hi < x0 + 64) return -1;
+            if ((m.at - rptr[rr]) & 1u) return 1;
+            return rt == 0 ? 0 : 2;
+        };
         for (int w = sx >> 6; w <= (ex >> 6); ++w) {
+            // A word strictly inside the run is all ones, and so are its left and right neighbours: its only edges are
+            // straight top / bottom edges where the row above / below is outside background over the whole word -- known
+            // from the run list in LDS, no load (r04: a run of n words cost n dependent round trips of loads per thread;
+            // the full-frame blob of Oat's default window: 59 us of the kernel's 112).
+            if (sx < w * 64 && ex > w * 64 + 63) {
+                const int su = row_state(mu, r - 1, adj_up, w * 64), sd = row_state(md, r + 1, adj_dn, w * 64);
+                if (su >= 0 && sd >= 0) {
+                    if (su == 0 || sd == 0) {
+                        const long long n = nbits, yy = y;
+                        const long long sumx = n * (w * 64 + sh) + n * (n - 1) / 2;      // x over this thread's bits
+                        if (su == 0) { s00 += n * yy; s10 += yy * (2 * sumx - n); s01 += 2 * yy * yy * n; }
+                        if (sd == 0) { s00 -= n * yy; s10 -= yy * (2 * sumx + n); s01 -= 2 * yy * yy * n; }
+                    }
+                    continue;
+                }
+            }
             const int lo = max(sx - w * 64, 0), hi = min(ex - w * 64, 63);
             const u64 runbits = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull) & qbits;
             // the threads of a run need the same nine words: thread 0 of them fetches the run's row, thread 1
@@ -988,6 +1013,28 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
 #undef Q16
             unsigned cand = cq & ~(Lq & Rq & Uq & Dq);
             const int xbase = w * 64 + sh;
+            // Straight horizontal edges in closed form (r04).  A border pixel whose row above holds no foreground at all (the
+            // row is not in the run list: everything there is OUTSIDE) and whose left neighbour is set contributes the top edge
+            // (x, y) -> (x - 1, y): d = y, and the sums over a mask of such pixels need their count and the sum of their x --
+            // four popcounts -- instead of one trip of the serial loop below each; the bottom edge (x, y) -> (x + 1, y)
+            // likewise.  The top and the bottom row of a large blob are ALL such pixels: with Oat's default all-pass window
+            // (one full-frame contour, the reference's own benchmark case) a thread walked up to 256 of them, 168 us a
+            // 1 MP frame (profiles/r04x_posidet_default_trace.md).  Same int64 terms, same sums.
+            unsigned ptop = 0u, pbot = 0u;
+            if (!adj_up) ptop = cq & ~Uq & ~ULq & Lq;
+            if (!adj_dn) pbot = cq & ~Dq & ~DRq & Rq;
+            if (ptop | pbot) {
+                auto sum_x = [&](unsigned m) -> long long {         // sum of x over the set bits of m
+                    const int sb = __popc(m & 0xAAAAu) + 2 * __popc(m & 0xCCCCu) + 4 * __popc(m & 0xF0F0u) + 8 * __popc(m & 0xFF00u);
+                    return (long long)__popc(m) * xbase + sb;
+                };
+                const long long nt = __popc(ptop), nb = __popc(pbot), yy = y;
+                s00 += (nt - nb) * yy;
+                s10 += yy * (2 * sum_x(ptop) - nt) - yy * (2 * sum_x(pbot) + nb);
+                s01 += 2 * yy * yy * (nt - nb);
+                // a pixel goes through the loop only for the sides that are left
+                cand &= (~Lq | ~Rq | (~Uq & ~ptop) | (~Dq & ~pbot));
+            }
             while (cand) {
                 const int bi = __ffs((int)cand) - 1;
                 cand &= cand - 1u;
@@ -1005,7 +1052,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
                     if (DLq & bit) { qx = x - 1; qy = y + 1; } else if (Dq & bit) { qx = x; qy = y + 1; } else e = false;
                     OAT_EDGE()
                 }
-                if (!(Dq & bit) && (!adj_dn || root_at(md, r + 1, x) == 0)) {                 // bottom
+                if (!((Dq | pbot) & bit) && (!adj_dn || root_at(md, r + 1, x) == 0)) {        // bottom
                     e = true;
                     if (DRq & bit) { qx = x + 1; qy = y + 1; } else if (Rq & bit) { qx = x + 1; qy = y; } else e = false;
                     OAT_EDGE()
@@ -1015,7 +1062,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
                     if (URq & bit) { qx = x + 1; qy = y - 1; } else if (Uq & bit) { qx = x; qy = y - 1; } else e = false;
                     OAT_EDGE()
                 }
-                if (!(Uq & bit) && (!adj_up || root_at(mu, r - 1, x) == 0)) {                 // top
+                if (!((Uq | ptop) & bit) && (!adj_up || root_at(mu, r - 1, x) == 0)) {        // top
                     e = true;
                     if (ULq & bit) { qx = x - 1; qy = y - 1; } else if (Lq & bit) { qx = x - 1; qy = y; } else e = false;
                     OAT_EDGE()
