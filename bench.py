@@ -244,8 +244,9 @@ def cpu_baseline_one(wl, frames_seq, budget_s):
     _, _, _, seq_stage = cpu_time_pipeline(wl, frames_seq, best, best, False, budget_s / 12, 300)
     pipe = {}
     half, quarter = max(1, best // 2), max(1, best // 4)
-    for tf, tm in sorted({(quarter, half + quarter), (half, half), (half, best), (half, best + half), (best, half)}):
-        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 10, 2000)
+    for tf, tm in sorted({(quarter, half + quarter), (half, half), (half, best), (half, best + half), (best, half), (best, best),
+                          (best + half, half), (min(2 * best, max(hw // 2, 1)), best)}):
+        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 12, 2000)
         pipe[f"{tf}+{tm}+1"] = dict(value=fps, frames=n, seconds=el, stage_ms=st)
     pbest = max(pipe, key=lambda k: pipe[k]["value"])
     v_seq, v_pipe = legs[best]["value"], pipe[pbest]["value"]

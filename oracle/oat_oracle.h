@@ -79,6 +79,7 @@ oat_pool *oat_pool_create(void);
 void oat_pool_make_current(oat_pool *p);
 void oat_pool_run(void *(*fn)(void *), void *jobs, size_t stride, int njobs);
 int oat_pool_max(void);
+void oat_pool_set_cpu_offset(int offset);   /* default pool: first cpu (in the spread order) of its pinned workers */
 
 /* State inspection (tests / parity): per pixel, `nmixtures` entries. */
 void oat_mog2_set_state(oat_mog2 *m, const uint8_t *modes_used, const float *weight, const float *variance,

@@ -112,6 +112,14 @@ def _load():
 
 
 lib = _load()
+# several processes of one job on one host (torch.distributed.run: bench.py --gpus N): every process's pinned row workers
+# get their own stretch of the machine's cpus
+if os.environ.get("LOCAL_RANK") and os.environ.get("LOCAL_WORLD_SIZE"):
+    try:
+        _lr, _lw = int(os.environ["LOCAL_RANK"]), max(int(os.environ["LOCAL_WORLD_SIZE"]), 1)
+        lib.oat_pool_set_cpu_offset(_lr * ((os.cpu_count() or 1) // _lw))
+    except (ValueError, AttributeError):
+        pass
 _u8p = C.POINTER(C.c_uint8)
 
 
