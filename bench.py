@@ -328,7 +328,7 @@ def cpu_baseline(name, frames_seq):
 
 LAB_CALM = False
 DENSE_NOISE = 5       # amplitude of the dense leg's per-frame noise (--dense-noise)
-EARLY_BLOB = None     # None: the library's default (off); False / True: oatgpu_set_early_blob (--early-blob)
+EARLY_BLOB = None     # None: the library's default (by shape: one stream of 4 MP and more); False / True: oatgpu_set_early_blob (--early-blob)
 FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 

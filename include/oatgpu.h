@@ -182,14 +182,15 @@ int oatgpu_synchronize(oatgpu_ctx *ctx);
  * While a traffic audit is on (oatgpu_traffic_audit) GREY contexts launch one frame at a time. */
 int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
 
-/* Early dispatch of the blob-analysis workgroup (default OFF; a latency / throughput trade for saturated pipelines).  With
- * on = 1, on the pipelined device-frame path of steps of 4 MP and more, the big workgroups that label a step's masks
- * (findContours + moments, DetectorFunc.cpp:41-63) are submitted on a HIP stream of their own together with the step's other
- * kernels and WAIT ON THE DEVICE for their frames' row scans: they take their wave slots while the per-pixel kernel of an
- * earlier frame drains instead of queueing for them on the frame's critical path (row scan + blob analysis beside the
- * per-pixel kernel: 4K 117 -> 64 us, 16 x 1080p 427 -> 69 us) for 1-3 % of the frame rate.  Results are identical either way.
- * Keep it off under tools that serialise kernel dispatches -- a counter-collecting profiler (rocprofv3 --pmc) would let
- * the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is
+/* Early dispatch of the blob-analysis workgroup.  On the pipelined device-frame path of steps of 4 MP and more, the big
+ * workgroups that label a step's masks (findContours + moments, DetectorFunc.cpp:41-63) are submitted on a HIP stream of
+ * their own together with the step's other kernels and WAIT ON THE DEVICE for their frames' row scans: they take their
+ * wave slots while the per-pixel kernel of an earlier frame drains instead of queueing for them on the frame's critical path.
+ * on = -1 (the default): by shape -- contexts of ONE stream, whose per-pixel kernel then runs with one wave a workgroup
+ * (4K: 18.5 k -> 19.2 k fps); 0: never; 1: every eligible step (several streams: row scan + blob analysis beside the
+ * per-pixel kernel 16 x 1080p 427 -> 69 us for 1-3 % of the frame rate).  Results are identical either way.
+ * Switch it off (0) under tools that serialise kernel dispatches -- a counter-collecting profiler (rocprofv3 --pmc) would
+ * let the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is
  * redone by the global kernels: correct, but slow. */
 int oatgpu_set_early_blob(oatgpu_ctx *ctx, int32_t on);
 

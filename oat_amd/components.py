@@ -422,8 +422,9 @@ class HotPath(_Context):
         self._chk(self.lib.oatgpu_set_fusion(self.ctx, int(frames_per_launch)))
 
     def set_early_blob(self, on=True):
-        """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan (opt-in)."""
-        self._chk(self.lib.oatgpu_set_early_blob(self.ctx, 1 if on else 0))
+        """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan.
+        None: the library's choice by shape (one stream of 4 MP and more), True / False: forced."""
+        self._chk(self.lib.oatgpu_set_early_blob(self.ctx, -1 if on is None else (1 if on else 0)))
 
     def profile(self, every=1):
         """every = 0/False: off; 1/True: time every step; N: time every Nth step."""

@@ -119,6 +119,43 @@ __device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &d
     }
 }
 
+// a / b where the quotient needs none of the rescaling the compiler's IEEE division carries (v_div_scale x 2, v_div_fmas's
+// scale, v_div_fixup): the same reciprocal and the same five fused steps in the same order, hence the same bits, whenever b
+// and 1 / b are normal, |exponent(a) - exponent(b)| < 96 and a > 2^-103 -- the conditions under which v_div_scale_f32 leaves
+// both operands alone and v_div_fixup_f32 passes the quotient through -- and whenever a == 0 and b is finite and positive
+// (every step is then exactly 0).  8 vector instructions instead of 11; 13 such divisions a frame sit in the unrolled mode
+// blocks, each issued by every wave that holds a single lane needing it.  Measured (profiles/r05d_fastdiv_ab.txt): dense 4K
+// model 282 -> 270 us per two-frame launch, everyday one-frame launch 77.6 -> 76.4 us; the everyday two-frame launch does
+// not move (19 of its 461 vector instructions per wave go, it is not bound by them alone).
+// The launcher (launch_mog_fused) guarantees the operands: a rate is 0 or in [2^-40, 1], a pruning threshold at least
+// 2^-60 and a model's weights 0 or in [2^-62, 4] (a model this library evolved; an imported one is checked) -- any other
+// launch runs the instantiations that keep the compiler's division (FD = false: the audit ones).
+template <bool FD>
+__device__ __forceinline__ float div_inrange(float a, float b)
+{
+    if (!FD) return a / b;
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float t = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(t, r, q);
+}
+// alphaT / weight at a fit site.  FROZEN == 1 (every rate of the launch is 0): 0 / weight is +0 for every positive finite
+// weight, whatever the model holds -- one v_cmp_class_f32, the division itself only on lanes whose weight is anything else.
+template <int FROZEN>
+__device__ __forceinline__ float rate_over_weight(float alphaT, float weight)
+{
+    if (FROZEN == 1) {
+        float k = 0.f;
+        if (!__builtin_amdgcn_classf(weight, 0x100 | 0x80)) k = alphaT / weight;      // not (+normal | +denormal)
+        return k;
+    }
+    return div_inrange<FROZEN == 0>(alphaT, weight);
+}
+
 // Iteration MODE of the mode loop on a register resident mixture.
 // dvm: bit k set when mode k's variance/mean registers were written.
 // CH = 3 (BGR) or 1 (GREY: the reference's generic-channel loops, which start their sums at 0.f --
@@ -141,7 +178,7 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 c.fits = true;
                 fit_here = true;
                 weight += alphaT;
-                const float k = alphaT / weight;
+                const float k = rate_over_weight<FROZEN>(alphaT, weight);
                 const float o0 = rm<0>(s, MODE), o1 = CH == 3 ? rm<1>(s, MODE) : 0.f, o2 = CH == 3 ? rm<2>(s, MODE) : 0.f;
                 const float n0 = o0 - k * d0, n1 = CH == 3 ? o1 - k * d1 : 0.f, n2 = CH == 3 ? o2 - k * d2 : 0.f;
                 set_rm<0>(s, MODE, n0);
@@ -200,14 +237,14 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
 // the test is dead code: the fused path returns 255 for every foreground pixel without walking the modes.  (On a dense
 // model a few lanes of most waves leave the background and every wave walked detectShadowGMM's five modes for them:
 // ~500 of the streaming-load instantiation's 1 266 vector instructions a wave, profiles/r03n_dead_shadow_test.txt.)
-template <int CH, bool TUP>
+template <int CH, bool TUP, int FROZEN>
 __device__ __forceinline__ int mog2_finish(PxModel<CH, TUP> &s, PxLoop &c, int nentry, int &nmodes_out, float x0, float x1,
                                            float x2, const MogParams &P, float alphaT, float alpha1, unsigned &dvm,
                                            bool &wchg, bool shadow_matters)
 {
     int nmodes = c.nmodes;
     // renormalise
-    const float inv = 1.f / c.total;
+    const float inv = div_inrange<FROZEN != 2>(1.f, c.total);
     wchg = (alphaT > 0.f) || (inv != 1.f);
 #pragma unroll
     for (int mode = 0; mode < kMaxMix; ++mode)
@@ -277,16 +314,16 @@ __device__ __forceinline__ int mog2_finish(PxModel<CH, TUP> &s, PxLoop &c, int n
 // RGB2HSV_b tables: sdiv[i] = cvRound((255<<12)/i), hdiv[i] = cvRound((180<<12)/(6 i)).
 // Neither quotient ever lands on .5 (255<<12 = 2^12*255, 180<<12/6 = 2^13*15), so
 // round-half-even == floor(q + 1/2) == floor((2n + i) / (2i)).  The quotient is taken in fp32:
-// numerator < 2^22 and denominator <= 510 are exact floats, the correctly rounded quotient is off by
-// < 1/(4i) while the exact one is at least 1/(2i) away from the next integer, so floor() is exact
-// (checked against the integer form for all 255 entries in tests/test_abi_exports.py) -- and a float
-// division is ~4x cheaper than an integer one, which matters at two table entries per pixel.
+// numerator < 2^22 and denominator <= 510 are exact floats, and the exact quotient is at least 1/(2i) away from
+// the next integer, so floor() of an fp32 quotient that is good to a few ulp is exact (hsv_sdiv / hsv_hdiv below;
+// checked against the integer form for all 255 entries in tests/test_abi_exports.py).
+__device__ __forceinline__ int hsv_sdiv(int i);
+__device__ __forceinline__ int hsv_hdiv(int i);
 __device__ __forceinline__ void hsv_tables_init(int *sdiv, int *hdiv)
 {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        const float d = (float)(2 * i);
-        sdiv[i] = i ? (int)floorf((float)(2 * (255 << 12) + i) / d) : 0;
-        hdiv[i] = i ? (int)floorf((float)(2 * ((180 << 12) / 6) + i) / d) : 0;
+        sdiv[i] = hsv_sdiv(i);
+        hdiv[i] = hsv_hdiv(i);
     }
 }
 
@@ -306,8 +343,13 @@ __device__ __forceinline__ void bgr2hsv_px(int b, int g, int r, const int *sdiv,
 // The same table entries computed on the spot (hsv_tables_init's exact fp32 quotients): K1 needs two entries per
 // FOREGROUND pixel, and building both 256-entry tables per 256-pixel workgroup costs every pixel two quotients
 // plus LDS traffic and a barrier -- the inline form costs foreground pixels the same and background pixels nothing.
-__device__ __forceinline__ int hsv_sdiv(int i) { return i ? (int)floorf((float)(2 * (255 << 12) + i) / (float)(2 * i)) : 0; }
-__device__ __forceinline__ int hsv_hdiv(int i) { return i ? (int)floorf((float)(2 * ((180 << 12) / 6) + i) / (float)(2 * i)) : 0; }
+// (r05) the quotient as numerator * v_rcp_f32(denominator), 2 vector instructions instead of the 11 of an IEEE division:
+// v_rcp_f32 is good to 1 ulp and the product rounds once more, so the result is within 1.5 * 2^-23 of the exact quotient
+// q <= 2^20 / i + 1/2, i.e. off by < 0.19 / i, while q lies at least 1 / (2i) away from the next integer (above): floor()
+// still lands on the same integer.  tests/test_abi_exports.py checks every entry with the reciprocal off by one ulp either
+// way, test_bgr2hsv_exhaustive_256cubed runs all 2^24 colours through tables built with these very functions.
+__device__ __forceinline__ int hsv_sdiv(int i) { return i ? (int)floorf((float)(2 * (255 << 12) + i) * __builtin_amdgcn_rcpf((float)(2 * i))) : 0; }
+__device__ __forceinline__ int hsv_hdiv(int i) { return i ? (int)floorf((float)(2 * ((180 << 12) / 6) + i) * __builtin_amdgcn_rcpf((float)(2 * i))) : 0; }
 __device__ __forceinline__ void bgr2hsv_inline(int b, int g, int r, int &h, int &s, int &v)
 {
     v = max(b, max(g, r));
@@ -467,9 +509,18 @@ __device__ __forceinline__ RangeParams karg_rp(KArgs ka)
     return r;
 }
 
-template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
-__global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
+// WG: threads a workgroup, 256 or 64.  The kernel has no LDS and no barrier, a wave is all that belongs together.  A
+// 4-wave workgroup takes one wave slot on each SIMD of a compute unit and gets in only when all four have one: slots stand
+// idle behind the slowest sibling (6.5 of 8 slots a SIMD are filled on average over a 4K launch, SQ_WAVE_CYCLES).  One wave a
+// workgroup refills every slot at once: 4K two-frame launch 102.3 -> 98.9 us, 16 x 1080p 401 -> 374 us, one frame a launch
+// 77.4 -> 75.2 us (profiles/r05f_k1_workgroup_size_ab.txt; 128 threads: 101.5 us, 512: 114.6 us) -- and starves the back
+// half, whose 16-wave workgroup now finds four free slots on every SIMD of a compute unit only when a launch drains
+// (k_blob_lds 110 -> 150 us beside K1 at 4K, 410 -> 750 us at 16 x 1080p): the pipeline gains only where the blob
+// workgroup is dispatched early and parked (oatgpu_api.hip, launch_jobs), and the launcher picks 64 only there.
+template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false, int WG = 256>
+__global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {
+    static_assert(WG == 256 || (WG == 64 && !AUDIT), "one wave a workgroup: the product instantiations only");
     static_assert(!FROZEN || (!AUDIT && !NTLD), "the frozen-model instantiations exist for the default-policy product kernels only");
     constexpr int kFrozenMode = AUDIT ? 2 : FROZEN ? 1 : 0;
     const bool audit_frz = AUDIT && a.audit_frozen != 0;
@@ -496,7 +547,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
     const unsigned nwords = (unsigned)(g.Palloc >> 6);
     unsigned widx;                                // mask word (= 64-pixel tile) this lane works in
     unsigned lpos;                                // ... and its bit in it
-    widx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    widx = blockIdx.x * (unsigned)(WG / 64) + (threadIdx.x >> 6);
     lpos = (unsigned)lane;
     const unsigned p = widx * kWavePx + lpos;
     const bool active = (int)(widx * kWavePx) < g.P;      // false: whole wave beyond the image (tail block)
@@ -770,7 +821,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
         cut_extra_ = (int)lp.fits + (int)lp.background + dvm + lp.nmodes + (int)lp.total;
         CUT(3);                      // + modes 1..4 of frame 1
 #endif
-        mask = mog2_finish<CH, TUP>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg, shadow_matters);
+        mask = mog2_finish<CH, TUP, kFrozenMode>(pm, lp, nold, nnew, x0, x1, x2, a.mp, a.alphaT, a.alpha1, dvm, wchg, shadow_matters);
     }
 #ifdef OATGPU_CUT
     cut_extra_ = mask + nnew + dvm + (int)wchg;
@@ -848,7 +899,7 @@ __global__ __launch_bounds__(256, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_
             mog2_mode<CH, 2, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
             mog2_mode<CH, 3, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
             mog2_mode<CH, 4, TUP, kFrozenMode>(pm, lq, y0, y1, y2, mp2, aT2, a12, pr2, dvm, audit_frz);
-            mask2 = mog2_finish<CH, TUP>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
+            mask2 = mog2_finish<CH, TUP, kFrozenMode>(pm, lq, nold2, nnew2, y0, y1, y2, mp2, aT2, a12, dvm, wchg2, shadow_matters);
         }
         if (mask2 == 0) { b = 0; gg = 0; r = 0; }          // frame.setTo(0, mask == 0)
         if (CH == 3) {
@@ -971,10 +1022,10 @@ void launch_stage_copy(const void *src_dev_visible, void *dst, size_t bytes, hip
 __global__ void k_nop() {}
 void launch_nop(hipStream_t st) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st); }
 
-template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
-static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
+template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN, int WG>
+static void launch_mog_wg(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
 {
-    const dim3 grid(g.Palloc / (4 * kWavePx), n_streams);
+    const dim3 grid(g.Palloc / ((WG / 64) * kWavePx), n_streams);
     unsigned lds = 0;
 #ifdef OATGPU_MEASURE                // (A/B builds only) OATGPU_K1_LDS=bytes: unused dynamic LDS per workgroup, which holds the
                                      // occupancy down -- 21 000 B = 7 workgroups a CU = 7 waves a SIMD, 26 000 = 6, 32 000 = 5
@@ -983,41 +1034,81 @@ static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, i
 #endif
     // stop != nullptr: the event rides on the dispatch packet's own completion signal (hipExtLaunchKernelGGL) -- no marker
     // packet of its own between this launch and the next one on the stream
-    if (stop) hipExtLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, nullptr, stop, 0, g, a, first_stream);
-    else hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN>), grid, dim3(256), lds, st, g, a, first_stream);
+    if (stop) hipExtLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN, WG>), grid, dim3(WG), lds, st, nullptr, stop, 0, g, a, first_stream);
+    else hipLaunchKernelGGL((k_mog_fused<CH, AUDIT, NTLD, NF, FROZEN, WG>), grid, dim3(WG), lds, st, g, a, first_stream);
+}
+template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false>
+static void launch_mog_ch(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop, int wg)
+{
+    if constexpr (!AUDIT) {
+        if (wg == 64) { launch_mog_wg<CH, AUDIT, NTLD, NF, FROZEN, 64>(g, a, first_stream, n_streams, st, stop); return; }
+    }
+    launch_mog_wg<CH, AUDIT, NTLD, NF, FROZEN, 256>(g, a, first_stream, n_streams, st, stop);
 }
 
-void launch_mog_fused(const Geom &g, const MogLaunch &a_in, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop)
+// div_inrange's operands (kernels above): a rate that is 0 or in [2^-40, 1] ...
+static bool rate_in_range(float aT, float prune)
+{
+    if (aT == 0.f) return true;
+    return aT >= 0x1p-40f && aT <= 1.f && -prune >= 0x1p-60f && -prune <= 0.5f * aT;       // (NaN fails every comparison)
+}
+
+static void launch_mog_pick(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop, int wg)
+{
+    if (a.frames2) {                     // two frames a launch (never fresh; audited for BGR only: the caller's business)
+        if (a.audit) {
+            launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st, stop, wg);
+        } else if (a.nt_loads) {
+            if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st, stop, wg);
+            else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st, stop, wg);
+        } else if (a.alphaT == 0.f && a.alphaT2 == 0.f) {      // a frozen model (Oat's default rate): mog2_mode, FROZEN
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st, stop, wg);
+            else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st, stop, wg);
+        } else {
+            if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st, stop, wg);
+            else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st, stop, wg);
+        }
+    } else if (a.audit) {                // (the audit counts bytes, not cache behaviour: default-policy loads)
+        if (a.channels == 1) launch_mog_ch<1, true, false, 1>(g, a, first_stream, n_streams, st, stop, wg);
+        else launch_mog_ch<3, true, false, 1>(g, a, first_stream, n_streams, st, stop, wg);
+    } else if (a.nt_loads) {
+        if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st, stop, wg);
+        else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st, stop, wg);
+    } else if (a.alphaT == 0.f && !a.fresh) {
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st, stop, wg);
+        else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st, stop, wg);
+    } else {
+        if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st, stop, wg);
+        else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st, stop, wg);
+    }
+}
+
+void launch_mog_fused(const Geom &g, const MogLaunch &a_in, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop,
+                      const MogLaunchOpts &o)
 {
     MogLaunch a = a_in;
     // what the product path below would pick for this launch (the audit instantiations count that kernel's stores)
     a.audit_frozen = (!a.nt_loads && a.alphaT == 0.f && (a.frames2 ? a.alphaT2 == 0.f : !a.fresh)) ? 1 : 0;
-    if (a.frames2) {                     // two frames a launch (never fresh; audited for BGR only: the caller's business)
-        if (a.audit) {
-            launch_mog_ch<3, true, false, 2>(g, a, first_stream, n_streams, st, stop);
-        } else if (a.nt_loads) {
-            if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st, stop);
-            else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st, stop);
-        } else if (a.alphaT == 0.f && a.alphaT2 == 0.f) {      // a frozen model (Oat's default rate): mog2_mode, FROZEN
-            if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st, stop);
-            else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st, stop);
-        } else {
-            if (a.channels == 1) launch_mog_ch<1, false, false, 2>(g, a, first_stream, n_streams, st, stop);
-            else launch_mog_ch<3, false, false, 2>(g, a, first_stream, n_streams, st, stop);
+    // The product instantiations divide by div_inrange.  A launch whose operands it does not cover -- a rate below 2^-40 or
+    // above 1, a pruning threshold below 2^-60 (complexity-reduction constant next to 0), a model that was imported with
+    // weights no run of this kernel produces -- goes, one frame a launch, through the instantiations that keep the
+    // compiler's division: the audit ones, counting into a sink of the context's.  Slower, and exact.
+    const bool in_range = !o.wild_model && rate_in_range(a.alphaT, a.prune) && (!a.frames2 || rate_in_range(a.alphaT2, a.prune2));
+    if (!a.audit && !in_range) {
+        a.audit = o.wild_sink;
+        if (a.frames2) {
+            MogLaunch a1 = a, a2 = a;
+            a1.frames2 = nullptr; a1.thr_bits2 = nullptr;
+            a1.audit_frozen = (!a1.nt_loads && a1.alphaT == 0.f && !a1.fresh) ? 1 : 0;
+            a2.frames = a.frames2; a2.thr_bits = a.thr_bits2; a2.alphaT = a.alphaT2; a2.alpha1 = a.alpha12; a2.prune = a.prune2;
+            a2.frames2 = nullptr; a2.thr_bits2 = nullptr;
+            a2.audit_frozen = (!a2.nt_loads && a2.alphaT == 0.f) ? 1 : 0;
+            launch_mog_pick(g, a1, first_stream, n_streams, st, nullptr, 256);
+            launch_mog_pick(g, a2, first_stream, n_streams, st, stop, 256);
+            return;
         }
-    } else if (a.audit) {                // (the audit counts bytes, not cache behaviour: default-policy loads)
-        if (a.channels == 1) launch_mog_ch<1, true, false, 1>(g, a, first_stream, n_streams, st, stop);
-        else launch_mog_ch<3, true, false, 1>(g, a, first_stream, n_streams, st, stop);
-    } else if (a.nt_loads) {
-        if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st, stop);
-        else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st, stop);
-    } else if (a.alphaT == 0.f && !a.fresh) {
-        if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st, stop);
-        else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st, stop);
-    } else {
-        if (a.channels == 1) launch_mog_ch<1, false, false, 1>(g, a, first_stream, n_streams, st, stop);
-        else launch_mog_ch<3, false, false, 1>(g, a, first_stream, n_streams, st, stop);
     }
+    launch_mog_pick(g, a, first_stream, n_streams, st, stop, o.wg);
 }
 
 // Model density for the cache-policy choice: ONE workgroup samples 16 384 counter bytes of a coarse lattice over

@@ -90,8 +90,11 @@ struct oatgpu_ctx {
     // parity, as on the plain path; the k_blob_lds workgroups of the step's frames are submitted with them as ONE launch on
     // B2 and wait on the device for their row scans' tickets.  Scratch sets 0 / 1 by frame parity; repairs of declined
     // frames use set 2 on B2.
-    bool early_blob = false;         // opt-in (oatgpu_set_early_blob): it shortens a saturated pipeline's back half by ~50 us and
-                                     // costs the per-pixel kernel 4 % (one parked workgroup at 4K) to 20 % (32 of them, 16 x 1080p)
+    int early_blob = -1;             // -1: by shape -- ONE stream of 4 MP and more, where the per-pixel kernel then runs with one wave
+                                     // a workgroup (k_mog_fused, WG): 4K 18.5 k -> 19.2 k fps, result 245 -> 250 us behind its frame
+                                     // (profiles/r05g_wg64_early_blob_ab.txt).  With 256-thread workgroups the parked workgroup costs
+                                     // the per-pixel kernel 4 % (one at 4K) to 20 % (32 of them, 16 x 1080p) and several streams gain
+                                     // nothing either way (r05h): off there.  0 / 1: oatgpu_set_early_blob
        // measurement: the early path's stream layout WITHOUT the parked workgroup (blob behind an event)
     bool stage_kernel = false;       // oatgpu_set_stage_copy(1): oatgpu_track_stage copies with a kernel reading the host frame in place
     int k1_stop_event = -1;          // the step's "K1 done" event rides on the last K1 launch's own completion signal (no marker
@@ -172,6 +175,8 @@ struct oatgpu_ctx {
 
     // traffic audit (oatgpu_traffic_audit)
     unsigned long long *audit_dev = nullptr;   // 8 counters
+    unsigned long long *wild_sink = nullptr;   // 8 counters nobody reads: launches outside div_inrange's operands (kernels_mog.hip)
+    std::vector<char> wild_model;              // [n_streams] 1: an imported model with weights no run of the kernel produces
     bool audit_on = false;
     long long audit_launches = 0;
 };
@@ -370,6 +375,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bb[0].thr);
     hipFree(c->kal.state);
     hipFree(c->audit_dev);
+    hipFree(c->wild_sink);
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
@@ -455,6 +461,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     }
     const size_t n = cfg->n_streams, npx = (size_t)g.H * g.W, PA = g.Palloc, NW = PA / 64;
     c->nframes.assign(n, 0);
+    c->wild_model.assign(n, 0);
     c->diff_have.assign(n, 0);
     c->bsub_have.assign(n, 0);
 
@@ -480,7 +487,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;
         if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
-    if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e) != 0;
+    if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
 
 
     if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0 ? 1 : 0;
@@ -518,6 +525,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok && hipHostMalloc((void **)&c->dens_host, 4 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) ok = false;
     if (ok && hipHostGetDevicePointer((void **)&c->dens_dev, c->dens_host, 0) != hipSuccess) ok = false;
     if (ok) memset(c->dens_host, 0, 4 * sizeof(unsigned));
+    if (ok && hipMalloc((void **)&c->wild_sink, 8 * sizeof(unsigned long long)) != hipSuccess) ok = false;
+    if (ok && hipMemset(c->wild_sink, 0, 8 * sizeof(unsigned long long)) != hipSuccess) ok = false;
     if (ok) {
         c->ring_ev.resize(c->ring_slots);
         c->back_graph.assign(c->ring_slots, nullptr);
@@ -639,7 +648,7 @@ extern "C" int oatgpu_set_stage_copy(oatgpu_ctx *c, int32_t mode)
 extern "C" int oatgpu_set_early_blob(oatgpu_ctx *c, int32_t on)
 {
     if (!c) return OATGPU_E_INVALID;
-    c->early_blob = on != 0;
+    c->early_blob = on < 0 ? -1 : on != 0;
     return OATGPU_OK;
 }
 
@@ -726,6 +735,15 @@ static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rat
     return a;
 }
 
+static MogLaunchOpts mog_launch_opts(oatgpu_ctx *c, int s0, int s1, int wg)
+{
+    MogLaunchOpts o;
+    o.wg = wg;
+    o.wild_sink = c->wild_sink;
+    for (int s = s0; s < s1; ++s) o.wild_model = o.wild_model || c->wild_model[(size_t)s] != 0;
+    return o;
+}
+
 static int check_stream_ix(oatgpu_ctx *c, int s)
 {
     if (!c) return OATGPU_E_INVALID;
@@ -794,7 +812,7 @@ static int mog_single(oatgpu_ctx *c, int s, const uint8_t *bgr_in, uint8_t *mask
     a.out_base = s;
     if (mask_out) a.out_mask = c->aux_a;
     if (bgr_out) a.out_bgr = c->aux_b;
-    launch_mog_fused(c->g, a, s, 1, c->stream);
+    launch_mog_fused(c->g, a, s, 1, c->stream, nullptr, mog_launch_opts(c, s, s + 1, 256));
     HIPCHK(c, hipGetLastError());
     if (bgr_out && !mask_out) return finish_frame(c, bgr_out, c->aux_b, npx * ch);       // (deferrable: the filter form)
     if (mask_out) HIPCHK(c, hipMemcpyAsync(mask_out, c->aux_a, npx, hipMemcpyDeviceToHost, c->stream));
@@ -1381,6 +1399,21 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             if (memcmp(&rates[(size_t)i * n + s1], &rates[(size_t)i * n + s0], sizeof(Rate)) != 0) return false;
         return true;
     };
+    // Small frames are bound by the host's launch calls (DESIGN.md section 4): the two back halves of a two-frame step
+    // then go down ONE B stream behind one wait, and one ring event -- recorded behind the second -- covers both
+    // results (8 runtime calls a step instead of 10): 3 x 320x240 78 k -> 108 k fps.  From about a megapixel a step on
+    // the back halves are long enough to want a stream each (one 1080p stream: 45.8 k fps apart, 38.9 k fps together).
+    const bool share_b = nj == 2 && (size_t)n * (size_t)c->g.P <= ((size_t)1 << 20) && !(c->expt & 1) && !c->use_graph && !c->serial;
+    // Early dispatch of the blob workgroup: device frames (the copy streams of the host-frame path share hardware queues
+    // with B streams, and a parked workgroup would hold the copies behind it up), steps of 4 MP and more (below that the
+    // per-pixel launches are short, the wait for wave slots with them, and the step is bound by the host's launch calls,
+    // of which this path makes two more: one 1080p stream 50 k -> 37 k fps), three B streams, a frame geometry the LDS
+    // kernel takes
+    // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
+    // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
+    const bool early_wanted = c->early_blob < 0 ? n == 1 : c->early_blob != 0;
+    const bool early = early_wanted && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
+                       c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
     // a second marker packet between two K1s on stream A)
     hipEvent_t k1_done = nullptr;
@@ -1406,7 +1439,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             const bool last = s1 == n && i + 1 == (pair ? 1 : nj);
             const bool ride_on = c->k1_stop_event < 0 ? (size_t)n * (size_t)c->g.P >= (size_t)4000000 : c->k1_stop_event != 0;
             const bool ride = last && ride_on && k1_done && !ps;
-            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr);
+            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr, mog_launch_opts(c, s0, s1, early ? 64 : 256));
             k1_done_recorded = k1_done_recorded || ride;
         }
         s0 = s1;
@@ -1429,20 +1462,6 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
 
     if (k1_done && !k1_done_recorded) HIPCHK(c, hipEventRecord(k1_done, A));
 
-    // Small frames are bound by the host's launch calls (DESIGN.md section 4): the two back halves of a two-frame step
-    // then go down ONE B stream behind one wait, and one ring event -- recorded behind the second -- covers both
-    // results (8 runtime calls a step instead of 10): 3 x 320x240 78 k -> 108 k fps.  From about a megapixel a step on
-    // the back halves are long enough to want a stream each (one 1080p stream: 45.8 k fps apart, 38.9 k fps together).
-    const bool share_b = nj == 2 && (size_t)n * (size_t)c->g.P <= ((size_t)1 << 20) && !(c->expt & 1) && !c->use_graph && !c->serial;
-    // Early dispatch of the blob workgroup: device frames (the copy streams of the host-frame path share hardware queues
-    // with B streams, and a parked workgroup would hold the copies behind it up), steps of 4 MP and more (below that the
-    // per-pixel launches are short, the wait for wave slots with them, and the step is bound by the host's launch calls,
-    // of which this path makes two more: one 1080p stream 50 k -> 37 k fps), three B streams, a frame geometry the LDS
-    // kernel takes
-    // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
-    // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
-    const bool early = c->early_blob && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
-                       c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
     if (c->last_early >= 0 && c->last_early != (int)early)          // the two paths use the scratch sets from different streams
         for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     c->last_early = (int)early;
@@ -1891,6 +1910,18 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state import failed: %s", hipGetErrorString(e));
     c->nframes[s] = nframes;
+    // The product kernels divide by the weights with div_inrange (kernels_mog.hip), which covers what a run of the kernel
+    // leaves in a model: a weight that is 0 or in [2^-62, 4].  A model holding anything else (hand-made, NaN, a weight of
+    // 1e-30) is taken as it is and advanced by the instantiations that keep the compiler's division.
+    bool wild = false;
+    for (size_t p = 0; p < npx && !wild; ++p) {
+        const size_t used = modes_used[p] < k ? modes_used[p] : k;
+        for (size_t m = 0; m < used; ++m) {
+            const float w = weight[p * k + m];
+            if (!(w == 0.f || (w >= 0x1p-62f && w <= 4.f))) { wild = true; break; }
+        }
+    }
+    c->wild_model[(size_t)s] = wild ? 1 : 0;
     return OATGPU_OK;
 }
 

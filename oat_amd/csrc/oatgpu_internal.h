@@ -107,7 +107,16 @@ struct MogLaunch {
 
 // --- kernels_mog.hip ---
 // stop: an event that becomes the launch's own completion (nullptr: none)
-void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop = nullptr);
+// wg: threads a workgroup, 256 or 64 (one wave a workgroup: kernels_mog.hip, k_mog_fused); wild_model: a stream of the launch
+// holds an imported model whose weights the kernel's in-range division does not cover; wild_sink: 8 device counters the
+// launches that keep the compiler's division count into (the audit instantiations; never nullptr in a context's launches)
+struct MogLaunchOpts {
+    int wg = 256;
+    bool wild_model = false;
+    unsigned long long *wild_sink = nullptr;
+};
+void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop,
+                      const MogLaunchOpts &o);
 // plain streaming kernels for the achievable-bandwidth measurement (n16 = number of 16-byte elements)
 void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st);
 void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);

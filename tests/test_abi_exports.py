@@ -76,3 +76,11 @@ def test_hsv_table_integer_formula_equals_cvround():
         for n, ref in (((255 << 12), (255 << 12) / (1.0 * i)), ((180 << 12) // 6, (180 << 12) / (6.0 * i))):
             q = int(np.floor(np.float32(2 * n + i) / np.float32(2 * i)))
             assert q == (2 * n + i) // (2 * i) == int(np.rint(ref))
+            # r05: the kernels take the quotient as numerator * v_rcp_f32(denominator); the instruction is good to 1 ulp, so
+            # the entry must come out right with the reciprocal one ulp off either way (and two, for margin)
+            r = np.float32(1.0) / np.float32(2 * i)
+            for ulps in (-2, -1, 0, 1, 2):
+                rr = r
+                for _ in range(abs(ulps)):
+                    rr = np.nextafter(rr, np.float32(np.inf if ulps > 0 else 0), dtype=np.float32)
+                assert int(np.floor(np.float32(2 * n + i) * rr)) == q, (i, n, ulps)

@@ -1458,6 +1458,72 @@ def test_two_frames_a_launch_equals_one_frame_a_launch(A, ch, restore, ring):
             assert _eq(a, b)          # every slot of every plane, live or not
 
 
+@pytest.mark.parametrize("ch,case", [(3, "tiny_rate"), (1, "tiny_rate"), (3, "wild_model"), (1, "wild_model"),
+                                     (3, "wild_model_frozen"), (3, "ct_zero"), (3, "rate_then_zero")])
+def test_launches_outside_the_in_range_division_stay_exact(A, ch, case):
+    """r05: the product instantiations of the per-pixel kernel divide with an 8-instruction sequence that equals the IEEE
+    division whenever no rescaling is needed (kernels_mog.hip, div_inrange).  The launcher sends everything else -- a rate
+    below 2^-40, a complexity-reduction constant of 0, an imported model with weights no run produces -- through the
+    instantiations that keep the compiler's division, one frame a launch.  Positions and the WHOLE model against the
+    oracle, on the pipelined two-frames-a-launch path; 'rate_then_zero' is the in-range mixed pair (a rate, then 0)."""
+    rows, cols, n, nframes = 70, 200, 2, 23
+    rng = np.random.default_rng(77 + ch)
+    lr = 1e-14 if case == "tiny_rate" else 0.02
+    over = dict(ct=0.0) if case == "ct_zero" else {}
+    kw = dict(n_streams=n, ring_depth=4, adaptation_coeff=lr, erode=2, dilate=4, area=(10.0, 1e6), channels=ch, **over)
+    if ch == 3:
+        kw.update(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+        p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=2, dilate=4, min_area=10.0,
+                         max_area=1e6)
+    else:
+        kw.update(h_thresh=(200, 256))
+        p = O.hsv_params(h_lo=200, h_hi=256, erode=2, dilate=4, min_area=10.0, max_area=1e6)
+    frames = _noisy_sequence(rng, n, rows, cols, ch, nframes, noise=7)
+    hp = A.HotPath(rows, cols, **kw)
+    hp.set_fusion(2)
+    orcs = [O.Mog2(rows, cols, ch, params=over) for _ in range(n)]
+    rates = [lr] * nframes
+    if case == "rate_then_zero":
+        rates = [lr if (t // 3) % 2 == 0 else 0.0 for t in range(nframes)]
+    start = 0
+    if case.startswith("wild_model"):
+        # six ordinary frames, then every weight of stream 0's model scaled on both sides -- by 2^12 (weights of thousands: one
+        # frame's renormalisation brings them back), or by 2^-80 under a frozen model (at a rate above 0 such weights are
+        # pruned at once and the all-zero mixture's 0 * inf is NaN territory, where oracle and kernel were never pinned):
+        # 1 / total then needs the rescaling the in-range sequence leaves out
+        start = 6
+        scale = np.float32(2.0 ** 12 if case == "wild_model" else 2.0 ** -80)
+        if case == "wild_model_frozen":
+            rates = [lr] * start + [0.0] * (nframes - start)
+        for t in range(start):
+            hp.learning_coeff_ = rates[t]
+            hp.enqueue(list(frames[t]))
+            got1 = hp.collect()
+            for s in range(n):
+                _same_detection(got1[s], O.chain_step(orcs[s], frames[t][s], rates[t], p)[0], ("warm", t, s))
+        nm, w, v, m, nf = hp.mog_state(0)
+        live = np.arange(w.shape[1])[None, :] < nm[:, None]
+        w = np.where(live, w * scale, 0).astype(np.float32)
+        v = np.where(live, v, 0).astype(np.float32); m = np.where(live[..., None], m, 0).astype(np.float32)
+        hp.set_mog_state(nm, w, v, m, nf, stream=0)
+        orcs[0].set_state(nm, w, v, m, nf)
+    got = []
+    for t in range(start, nframes):
+        hp.learning_coeff_ = rates[t]
+        hp.enqueue(list(frames[t]))
+        if hp.outstanding() >= 4:
+            got.append(hp.collect())
+    while hp.outstanding():
+        got.append(hp.collect())
+    for i, t in enumerate(range(start, nframes)):
+        for s in range(n):
+            want, _ = O.chain_step(orcs[s], frames[t][s], rates[t], p)
+            _same_detection(got[i][s], want, (case, t, s))
+    for s in range(n):
+        _same_state(hp.mog_state(s), orcs[s].state(), (case, s))
+    hp.close()
+
+
 @pytest.mark.parametrize("fusion", [1, 2])
 def test_frozen_model_is_read_only_except_where_the_update_changes_bits(A, fusion):
     """Learning rate 0 (Oat's default) runs K1's FROZEN instantiations: a fitted record goes back to memory only when the

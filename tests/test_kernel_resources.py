@@ -38,15 +38,21 @@ def test_per_pixel_kernel_register_allocation():
     assert os.path.exists(lib), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     md = kernel_metadata(lib)
     k1 = {n: m for n, m in md.items() if "k_mog_fused" in n}
-    assert len(k1) >= 15, sorted(k1)                              # CH x AUDIT x NTLD x NF x FROZEN as instantiated
+    assert len(k1) >= 27, sorted(k1)                              # CH x AUDIT x NTLD x NF x FROZEN x WG as instantiated
     for n, m in k1.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (n, m)     # no scratch, anywhere
         assert m["group_segment_fixed_size"] == 0, (n, m)                                      # K1 uses no LDS
-    # template arguments in the mangled name: ILi<CH>ELb<AUDIT>ELb<NTLD>ELi<NF>ELb<FROZEN>E
+    # template arguments in the mangled name: ILi<CH>ELb<AUDIT>ELb<NTLD>ELi<NF>ELb<FROZEN>ELi<WG>E
     def inst(ch, audit, ntld, nf, frozen):
+        """the 256-thread instantiation; its one-wave-a-workgroup twin (r05; product instantiations only) must allocate alike"""
         tag = f"ILi{ch}ELb{int(audit)}ELb{int(ntld)}ELi{nf}ELb{int(frozen)}E"
-        hit = [m for n, m in k1.items() if tag in n]
+        hit = [m for n, m in k1.items() if tag + "Li256E" in n]
         assert len(hit) == 1, tag
+        twin = [m for n, m in k1.items() if tag + "Li64E" in n]
+        assert len(twin) == (0 if audit else 1), tag
+        for t in twin:
+            assert t["vgpr_count"] <= hit[0]["vgpr_count"] and t["sgpr_count"] <= hit[0]["sgpr_count"] and \
+                t["sgpr_spill_count"] <= hit[0]["sgpr_spill_count"], (tag, t, hit[0])
         return hit[0]
     for frozen in (False, True):
         two = inst(3, False, False, 2, frozen)                    # the product kernel of the pipelined path
