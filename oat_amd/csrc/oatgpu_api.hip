@@ -101,6 +101,7 @@ struct oatgpu_ctx {
                                      // packet behind it on stream A): -1 by step size (>= 4 MP: +1..2.5 % at 4K; small steps are
                                      // bound by the host's calls, and hipExtLaunchKernel costs more of those: one 1080p stream -3 %),
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
+    int k1_wg_force = 0;             // measurement builds (OATGPU_K1_WG=64|256): the per-pixel kernel's workgroup size whatever the path
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
     unsigned early_frames = 0;       // frames that took the early path (their parity picks scratch set and row-scan stream)
@@ -488,6 +489,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
+    if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
 
     if (const char *e = measure_env("OATGPU_K1_STOP_EVENT")) c->k1_stop_event = atoi(e) != 0 ? 1 : 0;
@@ -1439,7 +1441,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             const bool last = s1 == n && i + 1 == (pair ? 1 : nj);
             const bool ride_on = c->k1_stop_event < 0 ? (size_t)n * (size_t)c->g.P >= (size_t)4000000 : c->k1_stop_event != 0;
             const bool ride = last && ride_on && k1_done && !ps;
-            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr, mog_launch_opts(c, s0, s1, early ? 64 : 256));
+            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr, mog_launch_opts(c, s0, s1, c->k1_wg_force ? c->k1_wg_force : early ? 64 : 256));
             k1_done_recorded = k1_done_recorded || ride;
         }
         s0 = s1;
