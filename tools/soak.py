@@ -18,6 +18,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def g_xy(g):
+    return g.x, g.y
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20000)
@@ -26,6 +30,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--ring", type=int, default=6)
     ap.add_argument("--pool", type=int, default=97)
+    ap.add_argument("--no-kalman", action="store_true",
+                    help="position filter off: with ONE stream of 4 MP and more the steps then take the early blob dispatch and "
+                         "the one-wave-a-workgroup per-pixel kernel (the library's default there, r05)")
+    ap.add_argument("--threads", type=int, default=8, help="row workers of the oracle chain")
     args = ap.parse_args()
 
     import torch
@@ -45,7 +53,8 @@ def main():
     kal = dict(dt=0.01, timeout=0.04, sigma_accel=25.0, sigma_noise=1.0)
     hp = oat_amd.HotPath(rows, cols, n_streams=n, ring_depth=args.ring, adaptation_coeff=0.01, erode=3, dilate=5,
                          area=(10.0, 1e5), **disc_hsv_window())
-    hp.set_kalman(True, **kal)
+    if not args.no_kalman:
+        hp.set_kalman(True, **kal)
     p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5,
                      min_area=10.0, max_area=1e5)
     orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
@@ -69,8 +78,9 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.frames):
         for s in range(n):
-            d, _ = O.chain_step(orc[s], pool[order[t]][s], 0.01, p, nthreads=8)
-            k = okal[s].filter(d["valid"], d["x"], d["y"])
+            d, _ = O.chain_step(orc[s], pool[order[t]][s], 0.01, p, nthreads=args.threads)
+            k = okal[s].filter(d["valid"], d["x"], d["y"]) if not args.no_kalman else dict(
+                position_valid=d["valid"], x=g_xy(got[t][s])[0], y=g_xy(got[t][s])[1], vx=got[t][s].vx, vy=got[t][s].vy)
             g = got[t][s]
             ok = (g.raw_valid == d["valid"] and g.position_valid == k["position_valid"]
                   and (g.x, g.y, g.vx, g.vy) == (k["x"], k["y"], k["vx"], k["vy"])
