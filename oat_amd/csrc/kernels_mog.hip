@@ -516,7 +516,7 @@ __device__ __forceinline__ RangeParams karg_rp(KArgs ka)
 // 77.4 -> 75.2 us (profiles/r05f_k1_workgroup_size_ab.txt; 128 threads: 101.5 us, 512: 114.6 us) -- and starves the back
 // half, whose 16-wave workgroup now finds four free slots on every SIMD of a compute unit only when a launch drains
 // (k_blob_lds 110 -> 150 us beside K1 at 4K, 410 -> 750 us at 16 x 1080p): the pipeline gains only where the blob
-// workgroup is dispatched early and parked (oatgpu_api.hip, launch_jobs), and the launcher picks 64 only there.
+// workgroup is dispatched early and parked, or where K1 is all that matters (a dense model): oatgpu_api.hip, launch_jobs.
 template <int CH, bool AUDIT, bool NTLD, int NF, bool FROZEN = false, int WG = 256>
 __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_fused(Geom g, MogLaunch a, int first_stream)
 {

@@ -1416,6 +1416,12 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     const bool early_wanted = c->early_blob < 0 ? n == 1 : c->early_blob != 0;
     const bool early = early_wanted && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
                        c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
+    // Threads a K1 workgroup (kernels_mog.hip, k_mog_fused): one wave a workgroup keeps every wave slot filled (K1 -3.5 % on
+    // an everyday 4K model, -5.5 % on a dense one) and starves the back half's workgroups of slots.  Taken where that
+    // does not come back as a lower frame rate: steps whose blob workgroup is already resident (early), and dense models
+    // (streaming-load launches: K1 is 5-10 x the back half, 4K 6 670 -> 7 110 fps, profiles/r05n_dense_wg64_ab.txt; a result
+    // is then ready ~230 us later, one K1 launch, because the blob workgroup gets in when the launch drains).
+    const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads) ? 64 : 256;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
     // a second marker packet between two K1s on stream A)
     hipEvent_t k1_done = nullptr;
@@ -1441,7 +1447,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             const bool last = s1 == n && i + 1 == (pair ? 1 : nj);
             const bool ride_on = c->k1_stop_event < 0 ? (size_t)n * (size_t)c->g.P >= (size_t)4000000 : c->k1_stop_event != 0;
             const bool ride = last && ride_on && k1_done && !ps;
-            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr, mog_launch_opts(c, s0, s1, c->k1_wg_force ? c->k1_wg_force : early ? 64 : 256));
+            launch_mog_fused(c->g, a, s0, s1 - s0, A, ride ? k1_done : nullptr, mog_launch_opts(c, s0, s1, k1_wg));
             k1_done_recorded = k1_done_recorded || ride;
         }
         s0 = s1;
