@@ -67,6 +67,17 @@ def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
     subprocess.run([os.path.join(host_bins, "oat-clean-hip"), addr], capture_output=True)
 
 
+def _consumers_ready(*addresses, timeout=30.0, settle=1.0):
+    """Every consumer touch()es the node of its SOURCE address when it starts (Source.h:118-139), and a token served before
+    that is a token the consumer never sees.  A fixed sleep was the test's assumption about process start-up time (one
+    failure on a slow box, r05q): wait for the node segments "/dev/shm/<addr>_node" instead, then a moment for the touch
+    itself."""
+    t_end = time.monotonic() + timeout
+    while time.monotonic() < t_end and not all(os.path.exists(f"/dev/shm/{a}_node") for a in addresses):
+        time.sleep(0.05)
+    time.sleep(settle)
+
+
 def _run_pipeline(host_bins, tmp_path, frames, fused, mog_args=(), config=None):
     rows, cols = frames[0].shape[:2]
     raw = tmp_path / "frames.raw"
@@ -85,7 +96,7 @@ def _run_pipeline(host_bins, tmp_path, frames, fused, mog_args=(), config=None):
         procs.append(subprocess.Popen([B("oat-posidet-hip"), "hsv", a_hsv, a_pos, "-a", "[20,100000]"] + det))
         procs.append(subprocess.Popen([B("oat-framefilt-hip"), "col", a_filt, a_hsv, "-C", "HSV"]))
         procs.append(subprocess.Popen([B("oat-framefilt-hip"), "mog", a_raw, a_filt, "-a", "0.01"] + list(mog_args)))
-    time.sleep(3.0)          # every consumer has touch()ed its node before the first token exists
+    _consumers_ready(a_pos, a_raw, *(() if fused else (a_filt, a_hsv)))   # every consumer has touch()ed its node before the first token exists
     feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols",
                                str(cols), "-n", str(len(frames)), "-r", "200"])
     try:
@@ -180,7 +191,7 @@ def test_grey_component_pipeline_matches_oracle(host_bins, tmp_path, fused):
                                    "-a", "[20,100000]"]),
                  subprocess.Popen([B("oat-framefilt-hip"), "mog", a_grey, a_filt, "-a", "0.01"])]
     procs.append(subprocess.Popen([B("oat-framefilt-hip"), "col", a_raw, a_grey, "-C", "GREY"]))
-    time.sleep(3.0)
+    _consumers_ready(a_pos, a_raw, a_grey, *(() if fused else (a_filt,)))
     feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols", str(cols),
                                "-n", str(n), "-r", "200"])
     try:
@@ -323,7 +334,7 @@ def _run_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200)
     tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
                                 "--ring", str(ring)] + list(extra))
-    time.sleep(3.0)
+    _consumers_ready(*srcs, *snks)
     feeders = []
     for s in range(n):
         raw = tmp_path / f"frames{s}.raw"
@@ -446,7 +457,7 @@ def _start_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=20
     tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
                                 "--ring", str(ring)] + list(extra), stderr=subprocess.PIPE, text=True)
-    time.sleep(3.0)
+    _consumers_ready(*srcs, *snks)
     feeders = []
     t0 = time.monotonic()
     for s in range(n):
@@ -567,7 +578,7 @@ def _grey_chain(host_bins, tmp_path, frames, filt_args, color="GREY"):
     reader = subprocess.Popen([B("oat-posi-cout"), a_pos], stdout=subprocess.PIPE, text=True)
     procs = [subprocess.Popen([B("oat-posidet-hip"), "thresh", a_f, a_pos, "-T", "[100,256]", "-a", "[4,100000]"]),
              subprocess.Popen([B("oat-framefilt-hip"), filt_args[0], a_raw, a_f] + list(filt_args[1:]))]
-    time.sleep(3.0)
+    _consumers_ready(a_pos, a_raw, a_f)
     feeder = subprocess.Popen([B("oat-frameserve-raw"), a_raw, "-f", str(raw), "--rows", str(rows), "--cols", str(cols),
                                "-C", color, "-n", str(len(frames)), "-r", "200"])
     try:
