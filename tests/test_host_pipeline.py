@@ -488,13 +488,14 @@ def test_failing_shard_ends_its_sinks_at_once_and_the_others_keep_their_tokens(h
     frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
     odd = SyntheticStream(120, 160, 63, n_discs=1, radius=6)
     frames.append([odd.frame(t, with_discs=t > 0) for t in range(n)])
-    tracker, readers, files, feeders, addrs, t0 = _start_batched(host_bins, tmp_path, frames, extra=("--gpu-index", "0,0"), fps=20)
+    tracker, readers, files, feeders, addrs, t0 = _start_batched(host_bins, tmp_path, frames, extra=("--gpu-index", "0,0"), fps=10)
     try:
-        # shard 1's consumers end while shard 0 (50 frames at 20 fps = 2.5 s) is still being served
+        # shard 1's consumers end while shard 0 (50 frames at 10 fps = 5 s) is still being served (the margin is for a slow
+        # box's process start-up, not for the component: the SINKs go END as soon as the shard's connect fails)
         for r in readers[2:]:
-            r.wait(timeout=2.0)
+            r.wait(timeout=4.0)
         t_end = time.monotonic() - t0
-        assert t_end < 1.5, t_end
+        assert t_end < 3.0, t_end
         assert readers[0].poll() is None and readers[1].poll() is None and tracker.poll() is None      # shard 0 goes on
         for r in readers[:2]:
             r.wait(timeout=120)
