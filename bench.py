@@ -248,6 +248,13 @@ def cpu_baseline_one(wl, frames_seq, budget_s):
                           (best + half, half), (min(2 * best, max(hw // 2, 1)), best)}):
         fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 12, 2000)
         pipe[f"{tf}+{tm}+1"] = dict(value=fps, frames=n, seconds=el, stage_ms=st)
+    # the two best splits once more (run-to-run spread of one split on one box: 78-112 fps at 4K, r05q): `value` is the best seen
+    for k in sorted(pipe, key=lambda k: -pipe[k]["value"])[:2]:
+        tf, tm = (int(x) for x in k.split("+")[:2])
+        fps, n, el, st = cpu_time_pipeline(wl, frames_seq, tf, tm, True, budget_s / 12, 2000)
+        pipe[k]["repeat"] = fps
+        if fps > pipe[k]["value"]:
+            pipe[k].update(value=fps, frames=n, seconds=el, stage_ms=st)
     pbest = max(pipe, key=lambda k: pipe[k]["value"])
     v_seq, v_pipe = legs[best]["value"], pipe[pbest]["value"]
     return dict(value=max(v_seq, v_pipe), unit="frames/s", cores=(best if v_seq >= v_pipe else sum(int(x) for x in pbest.split("+"))),
