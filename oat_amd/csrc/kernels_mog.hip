@@ -143,16 +143,10 @@ __device__ __forceinline__ float div_inrange(float a, float b)
     t = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(t, r, q);
 }
-// alphaT / weight at a fit site.  FROZEN == 1 (every rate of the launch is 0): 0 / weight is +0 for every positive finite
-// weight, whatever the model holds -- one v_cmp_class_f32, the division itself only on lanes whose weight is anything else.
+// alphaT / weight at a fit site (FROZEN == 1: reached only by lanes off the no-op path below -- the compiler's division)
 template <int FROZEN>
 __device__ __forceinline__ float rate_over_weight(float alphaT, float weight)
 {
-    if (FROZEN == 1) {
-        float k = 0.f;
-        if (!__builtin_amdgcn_classf(weight, 0x100 | 0x80)) k = alphaT / weight;      // not (+normal | +denormal)
-        return k;
-    }
     return div_inrange<FROZEN == 0>(alphaT, weight);
 }
 
@@ -178,6 +172,18 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 c.fits = true;
                 fit_here = true;
                 weight += alphaT;
+                // FROZEN == 1 -- every rate of the launch is 0, over a PLAIN model (the launcher's guarantee: means finite,
+                // below 2^20 and not -0.f, variances inside [varMin, varMax]; what a run of this kernel leaves, what an import is
+                // checked for): with a positive finite weight k = 0 / weight is +0, k * d is a zero, mean - zero is the mean,
+                // var + 0 * (dist2 - var) is var and the clamp leaves it -- the update is the identity, bit for bit, and is not
+                // computed (11 + 4 vector instructions a fit site that found out, every frame, that nothing had changed:
+                // two-frame 4K launch at rate 0 84.9 -> 79.9 us, 22.2 k -> 23.4 k fps, profiles/r05t_frozen_identity_update_ab.txt).
+                // A lane whose weight is anything else takes the update.
+                bool upd = true;
+#ifndef OATGPU_NO_FROZEN_NOOP         // (make variant DEFS=-DOATGPU_NO_FROZEN_NOOP: the A/B build)
+                if (FROZEN == 1) upd = !__builtin_amdgcn_classf(weight, 0x100 | 0x80);       // not (+normal | +denormal)
+#endif
+                if (upd) {
                 const float k = rate_over_weight<FROZEN>(alphaT, weight);
                 const float o0 = rm<0>(s, MODE), o1 = CH == 3 ? rm<1>(s, MODE) : 0.f, o2 = CH == 3 ? rm<2>(s, MODE) : 0.f;
                 const float n0 = o0 - k * d0, n1 = CH == 3 ? o1 - k * d1 : 0.f, n2 = CH == 3 ? o2 - k * d2 : 0.f;
@@ -203,6 +209,7 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                     dirty = __float_as_uint(n0) != __float_as_uint(o0) || __float_as_uint(n1) != __float_as_uint(o1) ||
                             __float_as_uint(n2) != __float_as_uint(o2) || __float_as_uint(varnew) != __float_as_uint(var);
                 if (dirty) dvm |= (1u << MODE);
+                }
                 // The reference bubbles the OLD weight up and then stores the new one
                 // into the final slot; carrying the new weight along is the same state.
                 s.w[MODE] = weight;
@@ -1061,7 +1068,7 @@ static void launch_mog_pick(const Geom &g, const MogLaunch &a, int first_stream,
         } else if (a.nt_loads) {
             if (a.channels == 1) launch_mog_ch<1, false, true, 2>(g, a, first_stream, n_streams, st, stop, wg);
             else launch_mog_ch<3, false, true, 2>(g, a, first_stream, n_streams, st, stop, wg);
-        } else if (a.alphaT == 0.f && a.alphaT2 == 0.f) {      // a frozen model (Oat's default rate): mog2_mode, FROZEN
+        } else if (a.audit_frozen) {                           // a frozen model (Oat's default rate): mog2_mode, FROZEN
             if (a.channels == 1) launch_mog_ch<1, false, false, 2, true>(g, a, first_stream, n_streams, st, stop, wg);
             else launch_mog_ch<3, false, false, 2, true>(g, a, first_stream, n_streams, st, stop, wg);
         } else {
@@ -1074,7 +1081,7 @@ static void launch_mog_pick(const Geom &g, const MogLaunch &a, int first_stream,
     } else if (a.nt_loads) {
         if (a.channels == 1) launch_mog_ch<1, false, true, 1>(g, a, first_stream, n_streams, st, stop, wg);
         else launch_mog_ch<3, false, true, 1>(g, a, first_stream, n_streams, st, stop, wg);
-    } else if (a.alphaT == 0.f && !a.fresh) {
+    } else if (a.audit_frozen) {
         if (a.channels == 1) launch_mog_ch<1, false, false, 1, true>(g, a, first_stream, n_streams, st, stop, wg);
         else launch_mog_ch<3, false, false, 1, true>(g, a, first_stream, n_streams, st, stop, wg);
     } else {
@@ -1088,7 +1095,9 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a_in, int first_stream, in
 {
     MogLaunch a = a_in;
     // what the product path below would pick for this launch (the audit instantiations count that kernel's stores)
-    a.audit_frozen = (!a.nt_loads && a.alphaT == 0.f && (a.frames2 ? a.alphaT2 == 0.f : !a.fresh)) ? 1 : 0;
+    // (frozen_ok: the configuration lets a plain model stay plain -- varMin <= varInit <= varMax; otherwise a launch at rate 0
+    // runs the instantiations that learn, which are exact at any rate)
+    a.audit_frozen = (o.frozen_ok && !a.nt_loads && a.alphaT == 0.f && (a.frames2 ? a.alphaT2 == 0.f : !a.fresh)) ? 1 : 0;
     // The product instantiations divide by div_inrange.  A launch whose operands it does not cover -- a rate below 2^-40 or
     // above 1, a pruning threshold below 2^-60 (complexity-reduction constant next to 0), a model that was imported with
     // weights no run of this kernel produces -- goes, one frame a launch, through the instantiations that keep the
@@ -1099,10 +1108,10 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a_in, int first_stream, in
         if (a.frames2) {
             MogLaunch a1 = a, a2 = a;
             a1.frames2 = nullptr; a1.thr_bits2 = nullptr;
-            a1.audit_frozen = (!a1.nt_loads && a1.alphaT == 0.f && !a1.fresh) ? 1 : 0;
+            a1.audit_frozen = (o.frozen_ok && !a1.nt_loads && a1.alphaT == 0.f && !a1.fresh) ? 1 : 0;
             a2.frames = a.frames2; a2.thr_bits = a.thr_bits2; a2.alphaT = a.alphaT2; a2.alpha1 = a.alpha12; a2.prune = a.prune2;
             a2.frames2 = nullptr; a2.thr_bits2 = nullptr;
-            a2.audit_frozen = (!a2.nt_loads && a2.alphaT == 0.f) ? 1 : 0;
+            a2.audit_frozen = (o.frozen_ok && !a2.nt_loads && a2.alphaT == 0.f) ? 1 : 0;
             launch_mog_pick(g, a1, first_stream, n_streams, st, nullptr, 256);
             launch_mog_pick(g, a2, first_stream, n_streams, st, stop, 256);
             return;

@@ -742,6 +742,7 @@ static MogLaunchOpts mog_launch_opts(oatgpu_ctx *c, int s0, int s1, int wg)
     MogLaunchOpts o;
     o.wg = wg;
     o.wild_sink = c->wild_sink;
+    o.frozen_ok = c->cfg.var_min <= c->cfg.var_init && c->cfg.var_init <= c->cfg.var_max && c->cfg.var_min > 0.f;
     for (int s = s0; s < s1; ++s) o.wild_model = o.wild_model || c->wild_model[(size_t)s] != 0;
     return o;
 }
@@ -1918,15 +1919,25 @@ extern "C" int oatgpu_mog_set_state(oatgpu_ctx *c, int32_t s, const uint8_t *mod
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, OATGPU_E_HIP, "state import failed: %s", hipGetErrorString(e));
     c->nframes[s] = nframes;
-    // The product kernels divide by the weights with div_inrange (kernels_mog.hip), which covers what a run of the kernel
-    // leaves in a model: a weight that is 0 or in [2^-62, 4].  A model holding anything else (hand-made, NaN, a weight of
-    // 1e-30) is taken as it is and advanced by the instantiations that keep the compiler's division.
+    // The product kernels rely on what a run of the kernel leaves in a model (kernels_mog.hip): a weight that is 0 or in
+    // [2^-62, 4] (div_inrange), means that are finite, below 2^20 and not -0.f and variances inside [var_min, var_max] (at
+    // rate 0 the update of a fitted mode is then the identity and is not computed).  A model holding anything else
+    // (hand-made, NaN, a weight of 1e-30, a variance outside the clamp) is taken as it is and advanced by the
+    // instantiations that keep the compiler's division and compute every update.
     bool wild = false;
+    const size_t chn = (size_t)c->cfg.channels;
     for (size_t p = 0; p < npx && !wild; ++p) {
         const size_t used = modes_used[p] < k ? modes_used[p] : k;
-        for (size_t m = 0; m < used; ++m) {
-            const float w = weight[p * k + m];
-            if (!(w == 0.f || (w >= 0x1p-62f && w <= 4.f))) { wild = true; break; }
+        for (size_t m = 0; m < used && !wild; ++m) {
+            const float w = weight[p * k + m], v = variance[p * k + m];
+            if (!(w == 0.f || (w >= 0x1p-62f && w <= 4.f))) wild = true;
+            if (!(v >= c->cfg.var_min && v <= c->cfg.var_max)) wild = true;
+            for (size_t ch = 0; ch < chn; ++ch) {
+                const float mu = mean[(p * k + m) * chn + ch];
+                uint32_t bits;
+                memcpy(&bits, &mu, sizeof bits);
+                if (!(mu > -0x1p20f && mu < 0x1p20f) || bits == 0x80000000u) wild = true;
+            }
         }
     }
     c->wild_model[(size_t)s] = wild ? 1 : 0;

@@ -108,11 +108,13 @@ struct MogLaunch {
 // --- kernels_mog.hip ---
 // stop: an event that becomes the launch's own completion (nullptr: none)
 // wg: threads a workgroup, 256 or 64 (one wave a workgroup: kernels_mog.hip, k_mog_fused); wild_model: a stream of the launch
-// holds an imported model whose weights the kernel's in-range division does not cover; wild_sink: 8 device counters the
+// holds an imported model that is not PLAIN -- weights the kernel's in-range division does not cover, means or variances on
+// which a rate-0 update is not the identity; wild_sink: 8 device counters the
 // launches that keep the compiler's division count into (the audit instantiations; never nullptr in a context's launches)
 struct MogLaunchOpts {
     int wg = 256;
     bool wild_model = false;
+    bool frozen_ok = true;       // varMin <= varInit <= varMax: the frozen-model instantiations may skip the identity update of a fit site
     unsigned long long *wild_sink = nullptr;
 };
 void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n_streams, hipStream_t st, hipEvent_t stop,

@@ -1542,6 +1542,13 @@ def test_frozen_model_is_read_only_except_where_the_update_changes_bits(A, fusio
     m[:, 0] = base.reshape(n, 3); m[:, 1] = 255 - base.reshape(n, 3)
     third = np.arange(n) % 3 == 0                                              # a third of the pixels: everyday, in-range model
     v[third, 0] = 15.0; w[third, 0] = 1.0; w[third, 1] = 0.0; nm[third] = 1; v[third, 1] = 0.0; m[third, 1] = 0.0
+    # (r05) ... some of them with a blue mean of -0.f under blue pixels of 0: d = -0 - 0 = -0, k * d = -0, mean - (-0) = +0 --
+    # the one way a rate-0 update of a sane-looking record changes bits.  (An imported model like this one is not PLAIN:
+    # oatgpu_mog_set_state says so and the launches compute every update.)
+    negz = third & (np.arange(n) % 15 == 0)
+    m[negz, 0, 0] = -0.0
+    for f in frames:
+        f.reshape(n, 3)[negz, 0] = 0
     hp = A.HotPath(rows, cols, adaptation_coeff=0.0, dilate=3, ring_depth=8)
     hp.set_fusion(fusion)
     orc = O.Mog2(rows, cols)
@@ -1561,6 +1568,8 @@ def test_frozen_model_is_read_only_except_where_the_update_changes_bits(A, fusio
     _same_state(hp.mog_state(), orc.state(), ("frozen", fusion))
     gv = hp.mog_state()[2]
     assert (gv[~third, 0] == 75.0).all() and (gv[third, 0] == 15.0).all()       # the clamp acted on the fitted mode, and was stored
+    gm = hp.mog_state()[3]
+    assert not np.signbit(gm[negz, 0, 0]).any()                                  # -0.f became +0.f, as in the reference
 
 
 def test_two_frames_a_launch_with_changing_rates_and_early_collects(A):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-frame-a-launch instantiations of K1 (r04): tools/k1_nf1_ab.sh OUT "variant[:lds_bytes] ..." [reps] [legs]
 #   variant = default | a `make variant` name; lds_bytes = OATGPU_K1_LDS (unused dynamic LDS that holds the occupancy down)
-#   legs: d = dense 4K model, s = everyday 4K model, z = everyday at learning rate 0
+#   legs: d = dense 4K model, s = everyday 4K model, z = everyday at learning rate 0 (Z: two frames a launch)
 out=${1:-gpurun_out/nf1}; combos=${2:-"default"}; reps=${3:-2}; legs=${4:-"d s"}
 mkdir -p $out
 for r in $(seq $reps); do
@@ -13,6 +13,7 @@ for r in $(seq $reps); do
         d) args="--workload 4k1 --dense-model --fusion 1 --steps 300 --warmup 1200 --quick --no-parity";;
         s) args="--workload 4k1 --fusion 1 --steps 1000 --quick --check-steps 16";;
         z) args="--workload 4k1 --fusion 1 --steps 1000 --quick --check-steps 16 --learning-rate 0 --age 60";;
+        Z) args="--workload 4k1 --fusion 2 --steps 1000 --quick --check-steps 16 --learning-rate 0 --age 60";;
         D) args="--workload 4k1 --dense-model --fusion 2 --steps 300 --warmup 1200 --quick --no-parity";;
         S) args="--workload 4k1 --fusion 2 --steps 1000 --quick --check-steps 16";;
       esac
