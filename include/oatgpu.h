@@ -398,7 +398,8 @@ int oatgpu_read_mask(oatgpu_ctx *ctx, int32_t stream_ix, int32_t which, uint8_t 
  * set_state / load take ANY model.  One that is not what a run of this library leaves -- a weight that is neither 0 nor in
  * [2^-62, 4], a mean that is not finite, at least 2^20 in size or -0.f, a variance outside [var_min, var_max] -- is advanced
  * by the kernel instantiations that keep the compiler's IEEE division and compute every update (exact for any input,
- * several times slower) for as long as the context lives; every other model by the product instantiations. */
+ * several times slower) until the stream is re-initialised or a plain model is imported; every other model by the product
+ * instantiations. */
 int oatgpu_mog_get_state(oatgpu_ctx *ctx, int32_t stream_ix, uint8_t *modes_used, float *weight,
                          float *variance, float *mean, int32_t *nframes);
 int oatgpu_mog_set_state(oatgpu_ctx *ctx, int32_t stream_ix, const uint8_t *modes_used,

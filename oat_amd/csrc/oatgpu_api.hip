@@ -691,7 +691,7 @@ static Rate mog_begin(oatgpu_ctx *c, int s, double learningRate)
     int &nf = c->nframes[s];
     const bool needToInitialize = nf == 0 || learningRate >= 1;
     r.fresh = needToInitialize ? 1 : 0;
-    if (needToInitialize) nf = 0;
+    if (needToInitialize) { nf = 0; c->wild_model[(size_t)s] = 0; }       // (the launch builds the stream's model anew: plain)
     ++nf;
     const int lim = 2 * nf < c->cfg.history ? 2 * nf : c->cfg.history;
     learningRate = (learningRate >= 0 && nf > 1) ? learningRate : 1. / lim;
