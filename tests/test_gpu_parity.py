@@ -1388,6 +1388,63 @@ def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
 
 # ------------------------------------------- two frames a launch (temporal fusion) --
 
+def test_two_one_stream_contexts_on_the_default_early_path_interleaved(A):
+    """r05: a context of ONE stream of >= 4 MP takes, by default, the early blob dispatch with the one-wave-a-workgroup
+    per-pixel kernel.  All contexts of a process share the device's four streams: two such contexts, their steps
+    interleaved and their rings kept full (parked blob workgroups of both queued on the one B2 stream, row scans of both on
+    B0 / B1), with a busy frame in each (declined -> repaired) -- every result equals the oracle's, and the pair is not
+    slower than a ticket time-out would make it."""
+    import time
+    import torch
+    rows, cols = 2048, 2176                                          # 4.46 MP a step
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    kw = dict(n_streams=1, ring_depth=4, adaptation_coeff=0.01, erode=3, dilate=5, area=(20.0, 1e6), **win)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=20.0, max_area=1e6)
+    nframes = 17
+    hps, orcs, devs, frames = [], [], [], []
+    for c in range(2):
+        rng = np.random.default_rng(900 + c)
+        base = rng.integers(90, 150, (rows, cols, 3)).astype(np.int16)
+        fs = []
+        for t in range(nframes):
+            f = np.clip(base + rng.integers(-5, 6, base.shape), 0, 255).astype(np.uint8)
+            if t > 0:
+                cy, cx = 40 + (37 * t + 300 * c) % 1900, 50 + (53 * t + 400 * c) % 2000
+                f[cy:cy + 30, cx:cx + 45] = (255, 64, 0)
+                if t == 6 + 3 * c:                                   # specks of the blob colour: the LDS kernel declines the frame
+                    f[rng.random((rows, cols)) < 0.01] = (255, 64, 0)
+            fs.append(f)
+        frames.append(fs)
+        devs.append([torch.from_numpy(f).cuda() for f in fs])
+        hp = A.HotPath(rows, cols, **kw)
+        hp.set_fusion(2)
+        hps.append(hp)
+        orcs.append(O.Mog2(rows, cols, 3))
+    torch.cuda.synchronize()
+    got = [[], []]
+    t0 = time.perf_counter()
+    for t in range(nframes):
+        for c in (0, 1) if t % 3 else (1, 0):                        # (the order of the two contexts varies)
+            hps[c].enqueue_dev(devs[c][t].data_ptr(), keepalive=devs[c][t])
+            if hps[c].outstanding() >= 4:
+                got[c].append(hps[c].collect())
+    for c in range(2):
+        while hps[c].outstanding():
+            got[c].append(hps[c].collect())
+    elapsed = time.perf_counter() - t0
+    hits = 0
+    for c in range(2):
+        assert len(got[c]) == nframes
+        for t in range(nframes):
+            want, _ = O.chain_step(orcs[c], frames[c][t], 0.01, p, nthreads=16)
+            _same_detection(got[c][t][0], want, (c, t))
+            hits += want["valid"]
+        _same_state(hps[c].mog_state(0), orcs[c].state(), ("ctx", c))
+        hps[c].close()
+    assert hits >= 2 * (nframes - 3)
+    assert elapsed < 1.0, elapsed                                    # 34 frames of ~60 us; a 100 ms ticket time-out a step would be seconds
+
+
 def _noisy_sequence(rng, n, rows, cols, ch, nframes, noise):
     """Frames whose pixels leave and re-enter their first mode often enough that every path between the two
     frames of a launch is taken: matched/matched, matched/full (the late record loads), full/matched, full/full."""
