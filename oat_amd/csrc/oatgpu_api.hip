@@ -95,7 +95,6 @@ struct oatgpu_ctx {
                                      // (profiles/r05g_wg64_early_blob_ab.txt).  With 256-thread workgroups the parked workgroup costs
                                      // the per-pixel kernel 4 % (one at 4K) to 20 % (32 of them, 16 x 1080p) and several streams gain
                                      // nothing either way (r05h): off there.  0 / 1: oatgpu_set_early_blob
-       // measurement: the early path's stream layout WITHOUT the parked workgroup (blob behind an event)
     bool stage_kernel = false;       // oatgpu_set_stage_copy(1): oatgpu_track_stage copies with a kernel reading the host frame in place
     int k1_stop_event = -1;          // the step's "K1 done" event rides on the last K1 launch's own completion signal (no marker
                                      // packet behind it on stream A): -1 by step size (>= 4 MP: +1..2.5 % at 4K; small steps are
