@@ -56,6 +56,8 @@ MODEL_BYTES_PER_PIXEL = 202     # ... and the model, read and written
 
 WORKLOADS = {
     "1080p1": dict(rows=1080, cols=1920, streams=1, erode=3, dilate=7),
+    "1080p2": dict(rows=1080, cols=1920, streams=2, erode=3, dilate=7),     # (lab sizes: not in extra_workloads)
+    "1080p4": dict(rows=1080, cols=1920, streams=4, erode=3, dilate=7),
     "1080p8": dict(rows=1080, cols=1920, streams=8, erode=3, dilate=7),
     "1080p16": dict(rows=1080, cols=1920, streams=16, erode=3, dilate=7),
     "4k1": dict(rows=2160, cols=3840, streams=1, erode=7, dilate=7),
@@ -335,7 +337,7 @@ def cpu_baseline(name, frames_seq):
 
 LAB_CALM = False
 DENSE_NOISE = 5       # amplitude of the dense leg's per-frame noise (--dense-noise)
-EARLY_BLOB = None     # None: the library's default (by shape: one stream of 4 MP and more); False / True: oatgpu_set_early_blob (--early-blob)
+EARLY_BLOB = None     # None: the library's default (by shape: one or two streams, 4 MP a step and more); False / True: oatgpu_set_early_blob (--early-blob)
 FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 
