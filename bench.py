@@ -56,7 +56,8 @@ MODEL_BYTES_PER_PIXEL = 202     # ... and the model, read and written
 
 WORKLOADS = {
     "1080p1": dict(rows=1080, cols=1920, streams=1, erode=3, dilate=7),
-    "1080p2": dict(rows=1080, cols=1920, streams=2, erode=3, dilate=7),     # (lab sizes: not in extra_workloads)
+    "qhd1": dict(rows=1440, cols=2560, streams=1, erode=5, dilate=7),       # (lab sizes: not in extra_workloads)
+    "1080p2": dict(rows=1080, cols=1920, streams=2, erode=3, dilate=7),
     "1080p4": dict(rows=1080, cols=1920, streams=4, erode=3, dilate=7),
     "1080p8": dict(rows=1080, cols=1920, streams=8, erode=3, dilate=7),
     "1080p16": dict(rows=1080, cols=1920, streams=16, erode=3, dilate=7),

@@ -100,6 +100,7 @@ struct oatgpu_ctx {
                                      // packet behind it on stream A): -1 by step size (>= 4 MP: +1..2.5 % at 4K; small steps are
                                      // bound by the host's calls, and hipExtLaunchKernel costs more of those: one 1080p stream -3 %),
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
+    size_t early_min_px = 4000000;   // pixels a step from which the early order is considered (measurement builds: OATGPU_EARLY_MIN_PX)
     int k1_wg_force = 0;             // measurement builds (OATGPU_K1_WG=64|256): the per-pixel kernel's workgroup size whatever the path
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
@@ -488,6 +489,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
+    if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
 
@@ -1415,7 +1417,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
     const bool early_wanted = c->early_blob < 0 ? n <= 2 : c->early_blob != 0;        // (r06a: 2 x 1080p 64.8 k -> 70.3 k fps, 4 x 1080p 73.0 k -> 65-72 k)
     const bool early = early_wanted && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
-                       c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= (size_t)4000000;
+                       c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= c->early_min_px;
     // Threads a K1 workgroup (kernels_mog.hip, k_mog_fused): one wave a workgroup keeps every wave slot filled (K1 -3.5 % on
     // an everyday 4K model, -5.5 % on a dense one) and starves the back half's workgroups of slots.  Taken where that
     // does not come back as a lower frame rate: steps whose blob workgroup is already resident (early), and dense models
