@@ -58,6 +58,7 @@ WORKLOADS = {
     "1080p1": dict(rows=1080, cols=1920, streams=1, erode=3, dilate=7),
     "qhd1": dict(rows=1440, cols=2560, streams=1, erode=5, dilate=7),       # (lab sizes: not in extra_workloads)
     "1080p2": dict(rows=1080, cols=1920, streams=2, erode=3, dilate=7),
+    "1080p3": dict(rows=1080, cols=1920, streams=3, erode=3, dilate=7),
     "1080p4": dict(rows=1080, cols=1920, streams=4, erode=3, dilate=7),
     "1080p8": dict(rows=1080, cols=1920, streams=8, erode=3, dilate=7),
     "1080p16": dict(rows=1080, cols=1920, streams=16, erode=3, dilate=7),
@@ -338,7 +339,7 @@ def cpu_baseline(name, frames_seq):
 
 LAB_CALM = False
 DENSE_NOISE = 5       # amplitude of the dense leg's per-frame noise (--dense-noise)
-EARLY_BLOB = None     # None: the library's default (by shape: one or two streams, 4 MP a step and more); False / True: oatgpu_set_early_blob (--early-blob)
+EARLY_BLOB = None     # None: the library's default (by shape: at most three streams, 4 MP a step and more); False / True: oatgpu_set_early_blob (--early-blob)
 FUSION = 2            # frames per launch of the fused per-pixel kernel on the pipelined path (--fusion; oatgpu_set_fusion)
 
 

@@ -186,8 +186,8 @@ int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
  * workgroups that label a step's masks (findContours + moments, DetectorFunc.cpp:41-63) are submitted on a HIP stream of
  * their own together with the step's other kernels and WAIT ON THE DEVICE for their frames' row scans: they take their
  * wave slots while the per-pixel kernel of an earlier frame drains instead of queueing for them on the frame's critical path.
- * on = -1 (the default): by shape -- contexts of one or two streams, whose per-pixel kernel then runs with one wave a
- * workgroup (4K: 18.5 k -> 19.2 k fps; 2 x 1080p: 64.8 k -> 70.3 k); 0: never; 1: every eligible step (several streams: row scan + blob analysis beside the
+ * on = -1 (the default): by shape -- contexts of at most three streams, whose per-pixel kernel then runs with one wave a
+ * workgroup (4K: 18.5 k -> 19.2 k fps; 2 x 1080p: 64.8 k -> 70.3 k; 3 x: 69.3 k -> 72-74 k; four and more lose); 0: never; 1: every eligible step (several streams: row scan + blob analysis beside the
  * per-pixel kernel 16 x 1080p 427 -> 69 us for 1-3 % of the frame rate).  Results are identical either way.
  * Switch it off (0) under tools that serialise kernel dispatches -- a counter-collecting profiler (rocprofv3 --pmc) would
  * let the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is

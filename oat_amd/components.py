@@ -423,7 +423,7 @@ class HotPath(_Context):
 
     def set_early_blob(self, on=True):
         """oatgpu_set_early_blob: the blob workgroup of a device-frame step is dispatched ahead of its row scan.
-        None: the library's choice by shape (one or two streams, 4 MP a step and more), True / False: forced."""
+        None: the library's choice by shape (at most three streams, 4 MP a step and more), True / False: forced."""
         self._chk(self.lib.oatgpu_set_early_blob(self.ctx, -1 if on is None else (1 if on else 0)))
 
     def profile(self, every=1):

@@ -90,7 +90,7 @@ struct oatgpu_ctx {
     // parity, as on the plain path; the k_blob_lds workgroups of the step's frames are submitted with them as ONE launch on
     // B2 and wait on the device for their row scans' tickets.  Scratch sets 0 / 1 by frame parity; repairs of declined
     // frames use set 2 on B2.
-    int early_blob = -1;             // -1: by shape -- ONE or TWO streams, 4 MP a step and more, where the per-pixel kernel then runs with one wave
+    int early_blob = -1;             // -1: by shape -- at most THREE streams, 4 MP a step and more, where the per-pixel kernel then runs with one wave
                                      // a workgroup (k_mog_fused, WG): 4K 18.5 k -> 19.2 k fps, result 245 -> 250 us behind its frame
                                      // (profiles/r05g_wg64_early_blob_ab.txt).  With 256-thread workgroups the parked workgroup costs
                                      // the per-pixel kernel 4 % (one at 4K) to 20 % (32 of them, 16 x 1080p) and several streams gain
@@ -1415,7 +1415,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // kernel takes
     // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
     // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
-    const bool early_wanted = c->early_blob < 0 ? n <= 2 : c->early_blob != 0;        // (r06a: 2 x 1080p 64.8 k -> 70.3 k fps, 4 x 1080p 73.0 k -> 65-72 k)
+    const bool early_wanted = c->early_blob < 0 ? n <= 3 : c->early_blob != 0;        // (r06a / r06e: 2 x 1080p 64.8 k -> 70.3 k fps, 3 x: 69.3 k -> 72-74 k, 4 x: 73.0 k -> 65-72 k)
     const bool early = early_wanted && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
                        c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= c->early_min_px;
     // Threads a K1 workgroup (kernels_mog.hip, k_mog_fused): one wave a workgroup keeps every wave slot filled (K1 -3.5 % on
