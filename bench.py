@@ -18,16 +18,22 @@ Workloads (BASELINE.json configs):
     1080p1   1 x 1920x1080 stream per GPU            (configs[1])
     vga1     1 x 640x480                             (configs[0] shape)
 
-What the one JSON line carries besides the contract's keys (N = 1 only, rank 0):
+Output.  Rank 0 prints ONE compact JSON line on stdout (<= 4 KB, numbers only: slim_line() below) -- the contract's
+keys plus
     roofline      the dominant kernel k_mog_fused against the 8 TB/s HBM peak on the leg where its 205
                   algorithmic B/px really move (`--dense-model` input at 4K, run inside this process):
-                  achieved / frac <= 1, traffic = PMC bytes per launch of that same leg, plus, for the
-                  benched (sparse) workload: frac_real (PMC bytes / kernel time), useful / moved B/px and
-                  the waste ratio from the kernel's own traffic audit
+                  achieved / frac <= 1, frac_one_frame (one frame a launch: SURVEY 8d verbatim), traffic = PMC
+                  bytes per launch of that same leg; frac_benched / waste_ratio for the benched (sparse) workload
     cpu_baseline  the oracle chain (a port of the reference's CPU path) on this host's cores
-    extra_workloads  1080p16, 1080p8, 1080p1 and vga1 measured the same way (shorter runs)
-    partition     N > 1: which global streams every rank owned, and every rank's own gate verdicts (both parity gates
-                  run on EVERY rank for every stream of its shard)
+    extra_workloads  {name: fps} for 1080p16, 1080p8, 1080p1 and vga1 measured the same way (shorter runs)
+    stage_ms, latency_us  device time of a frame through both halves; enqueue -> result-ready latency
+    partition     which global streams every rank owned and its gate verdict (N > 1: both gates on EVERY rank)
+    scatter_ingest  N > 1: the same hot path fed through the stream->rank scatter from rank 0 (RCCL send/recv)
+-- and writes EVERYTHING it measured (notes, thread-split tables, audits, PMC detail, timing blocks) to
+bench_detail.json beside this file and, as one line, to stderr.
+`--gpus N` IS an N-rank run: without WORLD_SIZE in the environment the script re-executes itself through
+`python -m torch.distributed.run --nproc-per-node N` (one rank per device; fewer devices than ranks is an error with the
+"nccl" backend); under a launcher whose world differs from --gpus it refuses to run.
 The PMC numbers come from rocprofv3 child processes of this very run (--no-pmc to skip them).
 """
 import argparse
@@ -75,6 +81,185 @@ MIN_TIMED_MS = 50.0             # below this a timed region says little (VERDICT
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+SLIM_LIMIT = 4096               # bytes of the ONE stdout line (a 21 KB line was not parsed by the driver)
+
+
+def _sig(x, n=5):
+    """Numbers of the stdout line carry n significant digits (the detail file has them in full)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{n}g}")
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def slim_line(full):
+    """The ONE stdout line, built from everything the run measured (`full`, which goes to bench_detail.json and to
+    stderr): the contract's keys plus compact numeric blocks, no prose.  Pure function of `full` (tests/test_bench_line.py
+    builds it from canned dicts and holds it to SLIM_LIMIT bytes)."""
+    r = full.get("roofline") or {}
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _sig(line[k], 7)
+    line["config"] = {"workload": cfg.get("name"), "streams_per_gpu": cfg.get("streams_per_gpu"), "rows": cfg.get("rows"),
+                      "cols": cfg.get("cols"), "erode": cfg.get("erode"), "dilate": cfg.get("dilate"),
+                      "learning_rate": cfg.get("learning_rate"), "mog_mixtures": 5,
+                      "frames_per_launch": _sig(cfg.get("frames_per_launch"), 3),
+                      "model_age_frames": cfg.get("model_age_frames"), "parallelism": cfg.get("parallelism")}
+    line["roofline"] = {
+        "kernel": r.get("kernel"), "bound": r.get("bound"), "peak": r.get("peak"), "unit": r.get("unit"),
+        "achieved": _sig(r.get("achieved")), "frac": _sig(r.get("frac"), 4),
+        "frac_one_frame": _sig(r.get("frac_one_frame"), 4), "frac_benched": _sig(r.get("frac_benched"), 4),
+        "bytes_per_launch": _sig(r.get("bytes_per_launch"), 8), "avg_launch_ms": _sig(r.get("avg_launch_ms")),
+        "avg_launch_ms_one_frame": _sig(_dig(r, "one_frame_a_launch", "avg_launch_ms")),
+        "traffic": _sig(r.get("traffic"), 8), "waste_ratio": _sig(r.get("waste_ratio"), 4),
+        "measured_stream_copy_GBps": _sig(r.get("measured_stream_copy_GBps")),
+        "leg": "4k1 dense (5 live modes a pixel)" if r.get("frac") is not None else None,
+        "benched_launch_ms": _sig(_dig(r, "benched_workload", "avg_launch_ms")),
+        "benched_traffic": _sig(_dig(r, "benched_workload", "traffic"), 8)}
+    cb = full.get("cpu_baseline")
+    if cb:
+        host = cb.get("host") or {}
+        line["cpu_baseline"] = {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind"), "method": cb.get("method"),
+                                "sample": cb.get("sample_short") or str(cb.get("sample", ""))[:100],
+                                "value_1thread": _sig(cb.get("value_1thread")), "nproc": host.get("nproc"),
+                                "physical_cores": host.get("physical_cores"), "cpu_model": host.get("cpu_model"),
+                                "other_sizes": {k: _sig(v.get("value")) for k, v in (cb.get("other_sizes") or {}).items()}}
+    else:
+        line["cpu_baseline"] = None
+    line["value_one_frame_a_launch"] = _sig(full.get("value_one_frame_a_launch"), 6)
+    line["value_default_learning_rate_0"] = _sig(full.get("value_default_learning_rate_0"), 6)
+    line["fps_per_gpu"] = _sig(full.get("fps_per_gpu"), 7)
+    line["stage_ms"] = {k: _sig(v, 4) for k, v in (full.get("stage_ms") or {}).items()}
+    line["latency_us"] = {k: _sig(v, 4) for k, v in (full.get("latency_us") or {}).items()} or None
+    line["parity"] = full.get("parity")
+    line["positions_found"] = full.get("positions_found")
+    line["positions_expected"] = full.get("positions_expected")
+    ew = full.get("extra_workloads")
+    line["extra_workloads"] = ({k: _sig(v.get("value"), 6) for k, v in ew.items()} if ew else None)
+    line["extra_parity"] = ({k: v.get("parity") for k, v in ew.items() if v.get("parity") != "ok"} or "ok") if ew else None
+    pl = full.get("pipeline")
+    if pl:
+        line["pipeline"] = {"framefilt_mog_1MP_fps": _sig(_dig(pl, "framefilt_mog_1MP", "fps")),
+                            "posidet_hsv_1MP_fps": _sig(_dig(pl, "posidet_hsv_1MP", "fps")),
+                            "track_1080p_latency_us_p50": _sig(_dig(pl, "track_1080p_latency", "free_running", "latency_us", "p50")),
+                            "track_1080p_latency_us_p99": _sig(_dig(pl, "track_1080p_latency", "free_running", "latency_us", "p99")),
+                            "track_8x1080p_fps": _sig(_dig(pl, "track_8x1080p", "fps_aggregate"))}
+    else:
+        line["pipeline"] = None
+    pt = full.get("partition") or {}
+    line["partition"] = {"rule": "stream s -> rank s // ceil(S/N)", "streams_total": pt.get("streams_total"),
+                         # [rank, device, first stream, one past the last, gate verdict, k_mog_fused ms]
+                         "ranks": [[q.get("rank"), q.get("device"), (q.get("streams") or [None, None])[0],
+                                    (q.get("streams") or [None, None])[1], q.get("parity"), _sig(q.get("k_mog_fused_ms"), 4)]
+                                   for q in (pt.get("per_rank") or [])]}
+    line["rccl"] = full.get("rccl")
+    sc = full.get("scatter_ingest")
+    line["scatter_ingest"] = ({k: (_sig(v) if not isinstance(v, str) else v) for k, v in sc.items()
+                               if k in ("fps", "ms_per_step", "bytes_per_peer", "parity", "steps", "depth", "backend", "error")}
+                              if sc else None)
+    line["device_open_retries"] = full.get("device_open_retries")
+    line["timed_region_ms"] = _sig(full.get("timed_region_ms"))
+    line["bench_wall_s"] = _sig(full.get("bench_wall_s"), 4)
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def emit(full):
+    """Rank 0: everything to bench_detail.json and stderr, the compact line -- and only it -- to stdout."""
+    slim = slim_line(full)
+    text = json.dumps(slim, separators=(",", ":"))
+    if len(text) > SLIM_LIMIT:          # never hand the driver a line it cannot parse: drop the optional blocks, largest first
+        for k in ("pipeline", "extra_workloads", "latency_us", "scatter_ingest", "partition"):
+            slim[k] = None
+            text = json.dumps(slim, separators=(",", ":"))
+            if len(text) <= SLIM_LIMIT:
+                break
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(full, f, indent=1, default=str)
+    except OSError as e:
+        log("bench_detail.json not written:", e)
+    log("bench detail: " + json.dumps(full, default=str))
+    print(text, flush=True)
+    return text
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks_if_asked(args, argv):
+    """`bench.py --gpus N` IS an N-rank run (VERDICT r04 missing-2).  Launched plainly (no WORLD_SIZE) with N > 1 the
+    script replaces itself by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`,
+    one rank per device; with the "nccl" (= RCCL) backend fewer visible devices than ranks is an error (rc 3), never a
+    silent N = 1.  Under a launcher (WORLD_SIZE set) the world must equal --gpus.  Returns the world size."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        world = int(env_world)
+        if args.gpus is not None and args.gpus != world:
+            log(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to run a "
+                f"mislabelled job")
+            sys.exit(2)
+        return world
+    n = args.gpus or 1
+    if n < 1:
+        log("bench.py: --gpus must be >= 1")
+        sys.exit(2)
+    if n == 1:
+        return 1
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < 1 or (args.backend == "nccl" and ndev < n):
+        log(f"bench.py: --gpus {n} needs {n} visible device(s), found {ndev} (backend {args.backend}: one rank per device; "
+            f"`--backend gloo` lets ranks share a device for control-flow smoke tests)")
+        sys.exit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: starting", n, "ranks:", " ".join(cmd))
+    sys.stdout.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def open_device_with_retry(dev, rank, attempts=6):
+    """First touch of the device by this rank.  The ranks of a job open a freshly booted device in the same instant, and the
+    first runtime call of one of them can fail transiently (seen once in six fresh-box runs of the 8-rank test, r04): bounded
+    retry with back-off, every failure printed with its text, the count carried into the line -- tolerated and VISIBLE, never
+    hidden by re-running the job."""
+    n = 0
+    for a in range(attempts):
+        try:
+            torch.cuda.set_device(dev)
+            torch.zeros(8, device=dev).sum().item()
+            return n
+        except Exception as e:
+            n += 1
+            log(f"[rank {rank}] opening {dev} failed (attempt {a + 1}/{attempts}): {type(e).__name__}: {str(e)[-300:]}")
+            if a + 1 == attempts:
+                raise
+            time.sleep(0.05 * (1 << a))
+    return n
 
 
 def pin_to_gpu_node(dev_index):
@@ -268,6 +453,8 @@ def cpu_baseline_one(wl, frames_seq, budget_s):
                        f"after stage (MOG2, HSV, inRange, morphology: rows over a persistent pool of {best} workers; contour following 1 "
                        f"thread, as OpenCV's findContours); and {pipe[pbest]['frames']} frames, {pipe[pbest]['seconds']:.1f} s, with the "
                        f"reference's three stages concurrent on consecutive frames (threads mog+col/morph+contours = {pbest})",
+                sample_short=f"{max(legs[best]['frames'], pipe[pbest]['frames'])} frames of one {wl['cols']}x{wl['rows']} stream "
+                             f"per leg, oracle chain, best of {len(legs)} sequential + {len(pipe)} stage-pipelined thread splits",
                 by_threads={str(k): v["value"] for k, v in legs.items()},
                 stage_ms_sequential=seq_stage,
                 pipelined={k: dict(value=v["value"], stage_ms=v["stage_ms"]) for k, v in pipe.items()},
@@ -461,9 +648,10 @@ class Leg:
         idx = [self.pool_index(self.step + i) for i in range(n)]
         return ((C.c_void_p * n)(*[self.pool[i].data_ptr() for i in idx]), (ffi.Position * (n * self.ns))())
 
-    def run(self, n, prepared=None, keep=False, done_s=None):
-        """n steps through the pipelined path; returns [n][ns] raw ffi.Position when keep.  done_s: a ctypes double
-        array of n entries that receives the time each step's result was collected (device-frame input only)."""
+    def run(self, n, prepared=None, keep=False, done_s=None, enq_s=None):
+        """n steps through the pipelined path; returns [n][ns] raw ffi.Position when keep.  done_s / enq_s: ctypes double
+        arrays of n entries that receive the time each step's result was collected / each step was handed over
+        (device-frame input only)."""
         import ctypes as C
         from oat_amd import ffi
         hp = self.hp
@@ -471,7 +659,7 @@ class Leg:
         if self.host_pool is None:
             seq, out = prepared if prepared is not None else self.prepare(n)
             if done_s is not None:
-                ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev_timed(ctx, seq, n, lr, out, done_s))
+                ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev_latency(ctx, seq, n, lr, out, done_s, enq_s))
             else:
                 ffi.check(lib, ctx, lib.oatgpu_track_sequence_dev(ctx, seq, n, lr, out))
             self.step += n
@@ -552,30 +740,49 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     if W:
         leg.run(W)
     # calibration (untimed, part of the warm-up as far as the model is concerned): how long does a step take?
-    cal = min(K, CAL_STEPS)
+    cal = CAL_STEPS
+    timed_dev = leg.host_pool is None
     hp.synchronize()
     t0 = time.perf_counter()
-    leg.run(cal)
+    cal_done = (C.c_double * cal)() if timed_dev else None
+    leg.run(cal, done_s=cal_done)
     hp.synchronize()
     t_cal = (time.perf_counter() - t0) / cal
+    if timed_dev:                # the steady half of it: result to result, free of the pipeline's fill and drain
+        t_cal = (cal_done[cal - 1] - cal_done[cal // 2 - 1]) / (cal - cal // 2)
     if reduce_max:
         t_cal = reduce_max([t_cal])[0]
-    timed_dev = leg.host_pool is None
     R = 1
+    R_max = max(2, 200000 // max(K, 1))
     if timed_dev:
-        R = int(min(max(2, -(-min_ms * 1e-3 // (t_cal * K)) + 1), max(2, 200000 // max(K, 1))))
-    n = R * K
-    hp.profile(prof_every if n < 64 else max(prof_every, 8))   # HIP events around K1 on every Nth step of the timed region
-    hp.profile_reset()
-    prepared = leg.prepare(n)
-    done = (C.c_double * n)() if timed_dev else None
-    barrier()
-    t0 = time.perf_counter()
-    out = leg.run(n, prepared, keep=True, done_s=done)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = hp.profile_read()
-    hp.profile(0)
+        # (sized by the calibration run's STEADY step time with a margin, and run again with more blocks should the region
+        # still end below min_ms: with --steps 20 a region sized by the whole calibration run, fill and drain included,
+        # came out at 43 ms -- VERDICT r04 weak-10)
+        R = int(min(max(2, -(-1.15 * min_ms * 1e-3 // (t_cal * K)) + 1), R_max))
+    attempts = skipped = 0
+    while True:
+        attempts += 1
+        if attempts > 1:
+            skipped += n                 # steps of a region that came out short: warm-up as far as the model and the gate go
+        n = R * K
+        hp.profile(prof_every if n < 64 else max(prof_every, 8))   # HIP events around K1 on every Nth step of the timed region
+        hp.profile_reset()
+        prepared = leg.prepare(n)
+        done = (C.c_double * n)() if timed_dev else None
+        enq = (C.c_double * n)() if timed_dev else None
+        barrier()
+        t0 = time.perf_counter()
+        out = leg.run(n, prepared, keep=True, done_s=done, enq_s=enq)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = hp.profile_read()
+        hp.profile(0)
+        short = [elapsed * 1e3 < min_ms]
+        if reduce_max:                   # every rank takes the same decision
+            short = [reduce_max([1.0 if short[0] else 0.0])[0] > 0.0]
+        if not timed_dev or not short[0] or attempts >= 3 or R >= R_max:
+            break
+        R = int(min(max(R + 1, R * 1.25 * min_ms / max(elapsed * 1e3, 1e-3) + 1), R_max))
     if timed_dev:
         ends = [done[(b + 1) * K - 1] for b in range(R)]
         blocks = [ends[0]] + [ends[b] - ends[b - 1] for b in range(1, R)]
@@ -603,9 +810,32 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     G = min(K, 256)              # the gate replays at most this many timed steps
     positions = [[Position2D.from_c(out[t * ns + s]) for s in range(ns)] for t in range(G)]
     found = sum(1 for t in range(n) for s_ in range(ns) if out[t * ns + s_].valid == 1)
+    lat = None
+    if timed_dev and n >= 8:     # enqueue -> result collected, per frame, steady part of the region (the ring is kept full)
+        l_ = sorted((done[i] - enq[i]) * 1e6 for i in range(min(n // 4, K), n))
+        lat = dict(p50=l_[len(l_) // 2], p99=l_[min(len(l_) - 1, int(len(l_) * 0.99))], ring_depth=RING)
     return dict(block_s=median, local_block_s=local_block, blocks=blocks, n_blocks=R, region_s=region[0], steps_timed=n, isolated_block_s=iso,
                 positions=positions, found=found, prof=prof, models=models, handover=handover, aged=aged,
-                gate_offset=W + cal, step_s_calibration=t_cal)
+                gate_offset=W + cal + skipped, step_s_calibration=t_cal, region_attempts=attempts,
+                saturated_latency_us=lat)
+
+
+def single_frame_latency(leg, n):
+    """One frame at a time through oatgpu_track_batch_dev (hand-over -> result, nothing else in flight): what a camera-paced
+    tracker waits for its position.  Continues the leg's model (untimed as far as `value` goes).  Microseconds."""
+    import ctypes as C
+    from oat_amd import ffi
+    hp = leg.hp
+    out = (ffi.Position * leg.ns)()
+    ts = []
+    for i in range(n):
+        ptr = C.c_void_p(leg.pool[leg.pool_index(leg.step)].data_ptr())
+        t0 = time.perf_counter()
+        ffi.check(hp.lib, hp.ctx, hp.lib.oatgpu_track_batch_dev(hp.ctx, ptr, hp.learning_coeff_, out))
+        ts.append((time.perf_counter() - t0) * 1e6)
+        leg.step += 1
+    ts = sorted(ts[n // 10:])
+    return dict(p50=ts[len(ts) // 2], p99=ts[min(len(ts) - 1, int(len(ts) * 0.99))], frames=len(ts))
 
 
 def k1_ms(prof):
@@ -664,6 +894,95 @@ def mode_histogram(leg):
                 mean_modes_used=float(nm.mean()), mean_live_modes=float(live.mean()))
 
 
+# -------------------------------------------------------- N > 1: scatter ingest --
+
+def scatter_leg(name, world, rank, dev, backend, steps, reduce_max, depth=2, gate_steps=3):
+    """N > 1, every rank: the hot path fed through the stream->rank scatter (north_star: "RCCL over xGMI only for the trivial
+    stream-to-rank scatter").  ALL frames originate on rank 0 -- a camera host -- and travel through
+    oat_amd.dist.FrameScatterPipe (send/recv per peer, `depth` slots, the hot path as consumer: the frames of step t+1 move
+    while step t computes); each rank runs its own shard's chain on what arrived.  Fresh models; the first gate_steps + 1
+    frames every rank RECEIVED are replayed through the oracle from scratch (masks' consequences: validity, exact contour
+    sums, centroids) -- the gate checks the transport and the chain together; the steps behind them are timed between two
+    barriers, max over ranks.  Returns a dict on every rank (rank 0's carries the gathered verdicts)."""
+    import torch.distributed as dist
+    import oracle_lib as O
+    from oat_amd.dist import FrameScatterPipe
+    from oat_amd.components import Position2D  # noqa: F401
+    wl = WORKLOADS[name]
+    rows, cols, ns = wl["rows"], wl["cols"], wl["streams"]
+    total, POOL, ring = ns * world, 6, 4
+    T, T0 = max(steps, gate_steps + 8), gate_steps + 2
+    hp = make_hotpath(wl, dev.index, ring_depth=ring, n_streams=ns)      # (oatgpu_track_enqueue_dev: one frame a launch)
+    pipe = FrameScatterPipe(total, (rows, cols, 3), dev, src=0, depth=depth, consumer=hp, via_host=(backend != "nccl"))
+    pool = make_pool_device(rows, cols, total, POOL, 4242, dev) if rank == 0 else None
+
+    def frames(t):
+        return pool[0 if t == 0 else t % POOL] if rank == 0 else None
+
+    def sync_all():
+        hp.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+    kept, results = [], []
+    try:
+        pipe.post(0, frames(0))
+        t_start = None
+        for t in range(T):
+            if t == T0:
+                while hp.outstanding():
+                    results.append(hp.collect())
+                sync_all()
+                t_start = time.perf_counter()
+            if t + 1 < T:
+                pipe.post(t + 1, frames(t + 1))
+            local = pipe.take(t)
+            if t <= gate_steps:
+                kept.append(local.cpu().numpy().copy())          # what ARRIVED, for the oracle
+            hp.enqueue_dev(local.data_ptr())
+            if hp.outstanding() == ring:
+                results.append(hp.collect())
+        while hp.outstanding():
+            results.append(hp.collect())
+        sync_all()
+        el = reduce_max([time.perf_counter() - t_start])[0]
+        found = sum(1 for r_ in results[T0:] for q in r_ if q.position_valid)
+        # ---- gate: the oracle from scratch over the frames this rank received ----
+        verdict = "ok"
+        p = oracle_params(wl)
+        for s_ in range(ns):
+            orc = oracle_mog(wl)
+            for t in range(gate_steps + 1):
+                want, _ = O.chain_step(orc, kept[t][s_], ALPHA, p, nthreads=host_threads())
+                g = results[t][s_]
+                if g.position_valid != want["valid"] or (want["valid"] and (
+                        (g.a00, g.a10, g.a01) != (want["a00"], want["a10"], want["a01"]) or
+                        abs(g.x - want["x"]) > 1e-4 or abs(g.y - want["y"]) > 1e-4)):
+                    verdict = f"rank {rank} stream {s_} frame {t}: differs from the oracle"
+                    break
+            if verdict != "ok":
+                break
+        rec = dict(rank=rank, parity=verdict, found=found)
+    except Exception as e:               # a broken transport must not take the per-rank-ingest line down with it
+        el, rec = None, dict(rank=rank, parity=f"error: {str(e)[-160:]}", found=0)
+        log(f"[rank {rank}] scatter leg failed:", e)
+    finally:
+        hp.close()
+    allrec = [None] * world
+    dist.all_gather_object(allrec, rec)
+    bad = [q for q in allrec if q["parity"] != "ok"]
+    out = dict(fps=(total * (T - T0) / el) if el else None, ms_per_step=(el / (T - T0) * 1e3) if el else None, steps=T - T0,
+               depth=depth, backend=backend, bytes_per_peer=pipe.bytes_per_peer, streams_total=total,
+               parity="ok" if not bad else bad[0]["parity"], per_rank=allrec,
+               positions_found=sum(q["found"] for q in allrec), positions_expected=total * (T - T0),
+               frames_per_launch=1,
+               what="all frames originate on rank 0 and reach their ranks through FrameScatterPipe (one send/recv per peer and "
+                    "step, double-buffered, the hot path as consumer); fresh models, one frame a launch; gate = the oracle from "
+                    "scratch over the first frames every rank RECEIVED")
+    pool = None
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------ PMC legs --
 
 def pmc_child(args):
@@ -671,8 +990,10 @@ def pmc_child(args):
     torch.cuda.set_device(0)
     leg = Leg(args.workload, 0, 0, dense=args.dense_model, pool=10 if args.dense_model else args.pool)
     # (the PMC passes run with --early-blob 0: rocprofv3 --pmc serialises kernel dispatches, and a blob workgroup dispatched
-    # ahead of its row scan would wait for a kernel that cannot start -- oatgpu_set_early_blob; the per-pixel kernel
-    # these passes count is not affected)
+    # ahead of its row scan would wait for a kernel that cannot start -- oatgpu_set_early_blob.  --k1-wg pins the per-pixel
+    # kernel to the workgroup size the BENCHED run used, so the counters are read on the very instantiation `value` ran)
+    if args.k1_wg:
+        leg.hp.set_k1_workgroup(args.k1_wg)
     leg.init()
     leg.age(args.age)
     leg.run(args.warmup)
@@ -681,7 +1002,7 @@ def pmc_child(args):
     leg.close()
 
 
-def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
+def pmc_pass(workload, dense, counter, W, K, timeout_s=240, k1_wg=0):
     """rocprofv3 --kernel-trace --pmc <counter> around a child of this script (counters in their own pass, as
     MI355X_MICROARCH.md prescribes).  Returns (avg counter value in KiB per k_mog_fused dispatch over the last K
     dispatches, avg duration us, dispatches) or None."""
@@ -692,7 +1013,7 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
     cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload, "--steps", str(K), "--warmup", str(W),
            "--age", str(AGE if not dense else 60), "--mog-restore-nmodes", str(RESTORE), "--learning-rate", str(ALPHA),
-           "--fusion", str(FUSION), "--early-blob", "0"]
+           "--fusion", str(FUSION), "--early-blob", "0", "--k1-wg", str(k1_wg)]
     if dense:
         cmd.append("--dense-model")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -727,7 +1048,7 @@ def pmc_pass(workload, dense, counter, W, K, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense):
+def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense, k1_wg_dense=0, k1_wg_benched=0):
     """HBM bytes per k_mog_fused launch of the dense leg and of the benched workload, as MI355X_MICROARCH.md
     prescribes: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled (on gfx950 it reports
     half the bytes of coalesced streaming reads).  `bytes_per_launch` = 2 x FETCH_SIZE + WRITE_SIZE.  The guide calls
@@ -739,8 +1060,8 @@ def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense):
                       "WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); *_calibrated = factors fitted "
                       "on the dense pass against the kernel's audited bytes")
     K = 48                      # one whole cycle of the 48-frame pool: the traffic varies with where the discs are
-    df = pmc_pass("4k1", True, "FETCH_SIZE", 12, K)
-    dw = pmc_pass("4k1", True, "WRITE_SIZE", 12, K)
+    df = pmc_pass("4k1", True, "FETCH_SIZE", 12, K, k1_wg=k1_wg_dense)
+    dw = pmc_pass("4k1", True, "WRITE_SIZE", 12, K, k1_wg=k1_wg_dense)
     if not df or not dw:
         return None
     fr = fw = None
@@ -757,13 +1078,13 @@ def pmc_traffic(workload, W, dense_audit_bytes, benched_is_dense):
         if fr and fw:
             d["bytes_per_launch_calibrated"] = fr * f[0] * 1024 + fw * w[0] * 1024
         return d
-    out["dense"] = entry(df, dw)
+    out["dense"] = entry(df, dw, k1_workgroup=k1_wg_dense)
     if benched_is_dense:
         return out
-    sf = pmc_pass(workload, False, "FETCH_SIZE", W, K)
-    sw = pmc_pass(workload, False, "WRITE_SIZE", W, K)
+    sf = pmc_pass(workload, False, "FETCH_SIZE", W, K, k1_wg=k1_wg_benched)
+    sw = pmc_pass(workload, False, "WRITE_SIZE", W, K, k1_wg=k1_wg_benched)
     if sf and sw:
-        out["benched"] = entry(sf, sw, workload=workload, warmup=W)
+        out["benched"] = entry(sf, sw, workload=workload, warmup=W, k1_workgroup=k1_wg_benched)
     return out
 
 
@@ -905,7 +1226,9 @@ def pipeline_block(device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = devices of this node (default 1, or the launcher's WORLD_SIZE).  N > 1 without a launcher: "
+                         "the script starts the N ranks itself through torch.distributed.run")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="4k1", choices=sorted(WORKLOADS))
@@ -944,11 +1267,20 @@ def main():
                          "two consecutive frames on one pass over the model (the library's default), 1 = one launch a frame")
     ap.add_argument("--early-blob", type=int, default=None, choices=[0, 1],
                     help="oatgpu_set_early_blob: 1 = the blob workgroup of a step is dispatched ahead of its row scan and waits "
-                         "for it on the device (shorter back half, slower per-pixel kernel); 0 = the plain launch order (the "
-                         "library's default)")
+                         "for it on the device; 0 = the plain launch order; default (no flag): the library's choice by shape "
+                         "(oatgpu_set_early_blob(-1): on for at most three streams at 4 MP a step and more)")
+    ap.add_argument("--k1-wg", type=int, default=0, choices=[0, 64, 256], help=argparse.SUPPRESS)   # PMC child: oatgpu_set_k1_workgroup
+    ap.add_argument("--detail-out", default=None, help="where the full result goes (default: bench_detail.json beside bench.py)")
+    ap.add_argument("--no-scatter", action="store_true", help="N > 1: skip the scatter_ingest leg (frames from rank 0 through "
+                                                              "the stream->rank scatter)")
+    ap.add_argument("--scatter-steps", type=int, default=200, help="steps of the scatter_ingest leg (N > 1)")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
+    world = 1 if args.pmc_child else spawn_ranks_if_asked(args, sys.argv[1:])
+    global DETAIL_PATH
+    if args.detail_out:
+        DETAIL_PATH = os.path.abspath(args.detail_out)
     global ALPHA, RESTORE, AGE, LAB_CALM, FUSION, DENSE_NOISE, EARLY_BLOB
     EARLY_BLOB = None if args.early_blob is None else bool(args.early_blob)
     DENSE_NOISE = args.dense_noise
@@ -963,7 +1295,6 @@ def main():
     if args.quick:
         args.no_pmc = args.no_extra = args.no_cpu_baseline = args.no_pipeline = True
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -977,8 +1308,8 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             local_rank = local_rank % max(ndev, 1)          # ranks may share a GPU in the smoke test
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    open_retries = open_device_with_retry(dev, rank)
     red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
     solo = world == 1
 
@@ -1044,6 +1375,25 @@ def main():
     else:
         n_found = n_found_local
 
+    k1_wg_benched, early_benched = leg.hp.last_step_shape()
+    early_timeouts = leg.hp.early_blob_timeouts()
+    one_lat = None
+    if rank == 0 and args.input == "device":
+        try:
+            one_lat = single_frame_latency(leg, 300)
+        except Exception as e:
+            log("single-frame latency probe failed:", e)
+    scatter = None
+    if world > 1 and not args.no_scatter and args.input == "device" and not args.dense_model:
+        try:
+            scatter = scatter_leg(args.workload, world, rank, dev, args.backend, args.scatter_steps, reduce_max)
+            if rank == 0:
+                log(f"scatter_ingest: {scatter['fps'] and round(scatter['fps'], 1)} fps, {scatter['ms_per_step']} ms/step, "
+                    f"{scatter['bytes_per_peer']} B/peer/step, parity {scatter['parity']}")
+        except Exception as e:
+            log(f"[rank {rank}] scatter leg failed:", e)
+            scatter = dict(error=str(e)[-200:], parity="error")
+
     per_rank = None
     if world > 1:
         # N > 1: every rank gates its own shard now (nothing else is timed in this process afterwards), then the
@@ -1051,7 +1401,9 @@ def main():
         my_par, my_detail = "skipped", None
         if want_gate:
             my_par, my_detail = gates(leg, tr["gate_offset"], K, positions, args.check_steps, models, handover)
+        from oat_amd import ffi as _ffi
         mine_rec = dict(rank=rank, device=local_rank, streams=[mine.start, mine.stop], parity=my_par,
+                        device_open_retries=open_retries + _ffi.load().oatgpu_device_open_retries(),
                         positions_found=n_found_local, block_ms=tr["block_s"] * 1e3,
                         k_mog_fused_ms=k1_ms(prof)[0], ms_per_step_local=tr["local_block_s"] / K * 1e3)
         per_rank = [None] * world
@@ -1160,6 +1512,7 @@ def main():
                        audit=aud, mode_histogram=hist)
     # ---- the leg where the algorithmic bytes really move: 4K, all five modes live on every pixel ----
     dense = None
+    k1_wg_dense = k1_wg_benched
     if solo and not args.no_dense_leg and args.input == "device":
         try:
             if args.dense_model and args.workload == "4k1":
@@ -1174,6 +1527,7 @@ def main():
                 b_prof = timed_run(dl, 100, 20, local_barrier(dl), 1, age_frames=60, export=False, min_ms=0.0)["prof"]
                 dr = timed_run(dl, 300, 1200, local_barrier(dl), 2, age_frames=60, export=False, min_ms=0.0)
                 d_prof = dr["prof"]
+                k1_wg_dense = dl.hp.last_step_shape()[0]
                 d_aud = audit(dl, 4)
                 dense = dict(avg_launch_ms=k1_ms(d_prof)[0], px_per_launch=3840 * 2160, steps=300,
                              ms_per_step=dr["block_s"] / 300 * 1e3, audit=d_aud, burst_avg_launch_ms=k1_ms(b_prof)[0],
@@ -1253,7 +1607,7 @@ def main():
         aud_bytes = ((da["sector32_read_B_per_px"] * dense["px_per_launch"],
                       da["sector32_write_B_per_px"] * dense["px_per_launch"])
                      if da and abs((dense.get("frames_per_launch") or 1.0) - da.get("frames_per_launch", 1.0)) < 1e-6 else None)
-        pmc = pmc_traffic(args.workload, W, aud_bytes, args.dense_model)
+        pmc = pmc_traffic(args.workload, W, aud_bytes, args.dense_model, k1_wg_dense=k1_wg_dense, k1_wg_benched=k1_wg_benched)
         log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
 
     roofline = {"bound": "hbm", "kernel": "k_mog_fused", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -1363,18 +1717,22 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic" if not LAB_CALM else "synthetic, LAB: no flickering pixels (not the SURVEY 8d input)",
+        # (SURVEY 8d's input puts ONE flickering pixel into every 64-pixel wave: every wave of the per-pixel kernel walks its
+        # no-fit paths -- the worst case for that kernel by construction, and the contract's input: VERDICT r04 weak-5)
+        "data": ("synthetic (SURVEY 8d; one flickering px in every 64-px wave: K1's worst case)" if not LAB_CALM
+                 else "synthetic, LAB: no flickering pixels (not the SURVEY 8d input)"),
         "config": {"workload": f"{ns} x {cols}x{rows} uchar3 stream(s) per GPU, MOG2(5 mixtures, lr {ALPHA}) + HSV + "
                                f"inRange + erode {wl['erode']} + dilate {wl['dilate']} + external-contour centroid",
                    "name": args.workload, "streams_per_gpu": ns, "rows": rows, "cols": cols,
+                   "erode": wl["erode"], "dilate": wl["dilate"],
                    "learning_rate": ALPHA, "mog_restore_nmodes": RESTORE, "model_age_frames": handover,
-                   "frames_per_launch": fpl,
+                   "frames_per_launch": fpl, "k1_workgroup": k1_wg_benched, "early_blob": early_benched,
                    "parallelism": f"streams sharded, {world} rank(s)"},
         "fps_per_gpu": fps / world,
         "partition": {"rule": "stream s -> rank s // ceil(S / N), contiguous blocks, for life (SURVEY 8e; oat_amd.dist.stream_partition)",
                       "streams_total": total_streams,
-                      "per_rank": per_rank if per_rank else [dict(rank=0, device=local_rank, streams=[0, ns], parity=None,
-                                                                  positions_found=n_found_local)]},
+                      "per_rank": per_rank if per_rank else [dict(rank=0, device=local_rank, streams=[0, ns], parity=parity,
+                                                                  positions_found=n_found_local, k_mog_fused_ms=mog_ms)]},
         "timing": {
             "method": f"{tr['n_blocks']} back-to-back blocks of exactly --steps {K} steps in ONE pipelined run between two "
                       "barriers (+ device synchronisation), sized so that the region lasts >= "
@@ -1398,6 +1756,17 @@ def main():
         "stage_ms": {"mog": mog_ms, "morph": prof["morph_ms"] / max(prof["steps"], 1),
                      "blob": prof["blob_ms"] / max(prof["steps"], 1),
                      "gpu_total": prof["total_ms"] / max(prof["steps"], 1)},
+        # time from a frame's hand-over to its result, (a) in the saturated run `value` is measured on (the ring is kept
+        # RING deep: mostly queueing) and (b) one frame at a time (oatgpu_track_batch_dev: what a camera-paced tracker sees)
+        "latency_us": dict(
+            saturated_p50=_dig(tr, "saturated_latency_us", "p50"), saturated_p99=_dig(tr, "saturated_latency_us", "p99"),
+            ring_depth=RING, single_p50=(one_lat or {}).get("p50"), single_p99=(one_lat or {}).get("p99")),
+        "early_blob_timeouts": early_timeouts,
+        "device_open_retries": (sum(q.get("device_open_retries", 0) for q in per_rank) if per_rank else open_retries),
+        "rccl": ({"ranks": world, "backend": args.backend,
+                  "version": ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+                 if world > 1 else None),
+        "scatter_ingest": scatter,
         "positions_found": n_found,
         "positions_expected": total_streams * tr["steps_timed"],
         "parity": parity,
@@ -1424,7 +1793,7 @@ def main():
     else:
         line["cpu_baseline"] = None
     line["bench_wall_s"] = time.perf_counter() - t_start
-    print(json.dumps(line), flush=True)
+    emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 7     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, oatgpu_set_deferred / _fetch_frame / _fetch_position, a failed pipelined launch is fatal for its context */
+#define OATGPU_ABI_VERSION 8     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, oatgpu_set_deferred / _fetch_frame / _fetch_position, a failed pipelined launch is fatal for its context; 8: oatgpu_track_sequence_dev_latency, oatgpu_device_open_retries, oatgpu_set_k1_workgroup, oatgpu_last_step_shape, oatgpu_early_blob_timeouts, a parked blob workgroup that times out switches early dispatch off for its context */
 
 enum {
     OATGPU_OK = 0,
@@ -153,6 +153,9 @@ const char *oatgpu_last_error(const oatgpu_ctx *ctx);
  * drives device i on that node's CPUs (host/oat_track_hip.cpp --gpu-index D0,D1,..): its launches, its shared-memory reads
  * and the staging copies then stay on the socket the GPU is attached to.  No reference counterpart. */
 int oatgpu_device_count(void);
+/* oatgpu_create opens its device with a bounded retry (several processes opening one freshly booted device at the same
+ * instant can see the first runtime calls fail transiently); this is how many retries this process has needed so far. */
+int oatgpu_device_open_retries(void);
 int oatgpu_device_numa_node(int32_t device);
 int oatgpu_host_register(void *ptr, size_t bytes);
 int oatgpu_host_unregister(void *ptr);
@@ -193,6 +196,18 @@ int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
  * let the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is
  * redone by the global kernels: correct, but slow. */
 int oatgpu_set_early_blob(oatgpu_ctx *ctx, int32_t on);
+/* Frames whose parked blob workgroup gave up after 100 ms because its row scan was not dispatched beside it (a tool that
+ * serialises kernel dispatches).  The first one switches early dispatch off for the context (oatgpu_last_error says so);
+ * the frames themselves were redone by the global kernels: results are unaffected. */
+int64_t oatgpu_early_blob_timeouts(const oatgpu_ctx *ctx);
+/* Threads of a workgroup of the fused per-pixel kernel on the pipelined path: 0 (default) by path -- 64 (one wave a
+ * workgroup) where the step's blob workgroup is dispatched early or the model is dense, 256 otherwise -- or 64 / 256
+ * whatever the path.  Results are identical.  For profiling the shipped instantiation under a tool that needs
+ * oatgpu_set_early_blob(0) (bench.py's counter passes). */
+int oatgpu_set_k1_workgroup(oatgpu_ctx *ctx, int32_t threads);
+/* How the latest pipelined step was launched: threads of a per-pixel workgroup (0 before the first step) and whether its
+ * blob workgroup was dispatched early.  Either pointer may be NULL. */
+int oatgpu_last_step_shape(const oatgpu_ctx *ctx, int32_t *k1_workgroup, int32_t *early_blob);
 
 /* Re-configure the detector between frames (what the reference's tuning GUI
  * mutates: HSVDetector.cpp:175-251). */
@@ -379,6 +394,10 @@ int oatgpu_track_sequence_dev(oatgpu_ctx *ctx, const void *const *frames_dev, in
  * (bench.py's block timing).  done_s may be NULL. */
 int oatgpu_track_sequence_dev_timed(oatgpu_ctx *ctx, const void *const *frames_dev, int32_t n_frames,
                                     double learning_rate, oatgpu_position *out, double *done_s);
+/* ... and WHEN each frame was handed to oatgpu_track_enqueue_dev inside the call: enq_s[t], same clock; done_s[t] -
+ * enq_s[t] is the time a frame spends in the pipeline with the ring kept full (bench.py latency_us).  Either may be NULL. */
+int oatgpu_track_sequence_dev_latency(oatgpu_ctx *ctx, const void *const *frames_dev, int32_t n_frames,
+                                      double learning_rate, oatgpu_position *out, double *done_s, double *enq_s);
 int oatgpu_track_outstanding(const oatgpu_ctx *ctx);
 
 /* ---- parity taps / model checkpoint (not in the reference; for tests and resume) ---- */

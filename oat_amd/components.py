@@ -426,6 +426,20 @@ class HotPath(_Context):
         None: the library's choice by shape (at most three streams, 4 MP a step and more), True / False: forced."""
         self._chk(self.lib.oatgpu_set_early_blob(self.ctx, -1 if on is None else (1 if on else 0)))
 
+    def set_k1_workgroup(self, threads=0):
+        """oatgpu_set_k1_workgroup: threads of a workgroup of the per-pixel kernel, 0 = by path (default), 64 or 256."""
+        self._chk(self.lib.oatgpu_set_k1_workgroup(self.ctx, int(threads)))
+
+    def last_step_shape(self):
+        """(threads of a per-pixel workgroup, blob workgroup dispatched early?) of the latest pipelined step."""
+        wg, early = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.oatgpu_last_step_shape(self.ctx, C.byref(wg), C.byref(early)))
+        return wg.value, bool(early.value)
+
+    def early_blob_timeouts(self):
+        """Frames whose parked blob workgroup gave up waiting for its row scan (oatgpu_early_blob_timeouts)."""
+        return int(self.lib.oatgpu_early_blob_timeouts(self.ctx))
+
     def profile(self, every=1):
         """every = 0/False: off; 1/True: time every step; N: time every Nth step."""
         self._chk(self.lib.oatgpu_profile_enable(self.ctx, int(every)))

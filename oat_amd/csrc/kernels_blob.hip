@@ -156,55 +156,68 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 }
 
 // ------------------------------------------------------------- row scan ------
-// One wavefront per image row, one lane per mask word (rows wider than 4096 px
-// loop in chunks of 64 words).  Applies the erosion (ERODE: the block first
-// erodes the 4 + dil_k - 1 rows its dilation windows touch into LDS) and the
+// One wavefront per image row at a time, one lane per mask word (rows wider than 4096 px
+// loop in chunks of 64 words).  Applies the erosion (ERODE: the workgroup first
+// erodes the ROWS + dil_k - 1 rows its dilation windows touch into LDS) and the
 // dilation (dil_k > 1) on the fly, writes the final mask (image frame zeroed,
 // as cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start
 // x of the run entering every word, and initialises the union-find at run heads.
-template <bool ERODE>
-__global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                 int first_stream, int clear_lds_ok)
+//
+// Workgroup shape <WAVES, ROWS>: a workgroup owns ROWS consecutive rows, wave w takes rows w, w + WAVES, ...
+//   <4, 4>  four waves, a row each: the shortest kernel on an idle device (12 us at 4K);
+//   <1, R>  ONE wave a workgroup, R rows one after the other.  Beside a per-pixel launch made of one-wave workgroups
+//           (k_mog_fused, WG = 64) a four-wave workgroup waits for four free wave slots on ONE compute unit at the same
+//           instant while every slot that frees up is refilled at once by the other queue: 12 us alone became 65-76 us
+//           beside it (profiles/r05q_kernel_stats_4k1_sparse.md).  A one-wave workgroup takes any slot, like its rival.
+template <bool ERODE, int WAVES, int ROWS>
+__global__ __launch_bounds__(64 * WAVES) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
+                                                        int first_stream, int clear_lds_ok)
 {
     extern __shared__ u64 er[];
+    constexpr int NT = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int y = blockIdx.x * 4 + wave;
     const int s = first_stream + blockIdx.y;
     const u64 *src_img = src_all + (size_t)s * (g.Palloc >> 6);
     const int dk = dil_k > 1 ? dil_k : 1;
     if (ERODE) {
-        const int r0 = blockIdx.x * 4 - dk / 2;
-        const int n = (4 + dk - 1) * g.words;
+        const int r0 = blockIdx.x * ROWS - dk / 2;
+        const int n = (ROWS + dk - 1) * g.words;
         // Masks are mostly empty: if no bit is set in any row the erosion windows of this workgroup touch, the
         // eroded rows are zero (an image row never erodes to more than it holds) -- one pass over the source
         // words instead of ero_k x 3 loads per eroded word (4K, 7 x 7: 960 loads instead of 12 600 per workgroup).
-        const int ya = max(r0 - ero_k / 2, 0), yb = min(r0 + (4 + dk - 1) - ero_k / 2 + ero_k - 1, g.H);   // source rows [ya, yb)
+        const int ya = max(r0 - ero_k / 2, 0), yb = min(r0 + (ROWS + dk - 1) - ero_k / 2 + ero_k - 1, g.H);   // source rows [ya, yb)
         u64 seen = 0ull;
-        for (int i = ya * g.words + threadIdx.x; i < yb * g.words; i += 256) seen |= src_img[i];
-        if (__syncthreads_or(seen != 0ull)) {
-            for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = ya * g.words + (int)threadIdx.x; i < yb * g.words; i += NT) seen |= src_img[i];
+        const bool any = WAVES == 1 ? __ballot(seen != 0ull) != 0ull : __syncthreads_or(seen != 0ull) != 0;
+        if (any) {
+            for (int i = threadIdx.x; i < n; i += NT) {
                 const int rr = i / g.words, w = i - rr * g.words;
                 const int yy = r0 + rr;
                 er[i] = (yy < 0 || yy >= g.H) ? 0ull : erode_word(g, src_img, yy, w, ero_k);
             }
         } else {
-            for (int i = threadIdx.x; i < n; i += 256) er[i] = 0ull;
+            for (int i = threadIdx.x; i < n; i += NT) er[i] = 0ull;
         }
         __syncthreads();
     }
-    if (y >= g.H) return;
+    int *parent = b.parent + (size_t)s * g.Palloc;
+    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
+    const int lastx = g.W - 1;
+
+#pragma unroll 1
+    for (int rr = wave; rr < ROWS; rr += WAVES) {
+    const int y = blockIdx.x * ROWS + rr;
+    if (y >= g.H) break;
     const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     u64 *morph = b.morph + woff;
     u64 *fin = b.fin + woff;
     u64 *trans = b.trans + woff;
     int *carry = b.carry + (size_t)s * g.H * g.words + (size_t)y * g.words;
-    int *parent = b.parent + (size_t)s * g.Palloc;
 
     if (y == 0 && lane == 0) { b.nroots[s] = 0u; if (clear_lds_ok) b.lds_ok[s] = 0u; }
 
     const bool frame_row = (y == 0) || (y == g.H - 1);
-    const int lastx = g.W - 1;
     int chunk_carry = 0;        // start x of the last run seen so far
     u64 chunk_prevbit = 0;      // pixel value just left of this chunk
     unsigned short *wpre = b.wpre + ((size_t)s * g.H + y) * g.words;
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
         const bool active = w < g.words;
         u64 F = 0;
         if (active && ERODE) {
-            F = dilate_word_lds(g, er, wave, w, dk);   // dk == 1: the eroded word itself
+            F = dilate_word_lds(g, er, rr, w, dk);   // dk == 1: the eroded word itself
             morph[w] = F;                            // the reference's threshold_frame_ (parity tap)
         } else if (active && dil_k > 1) {
             F = dilate_word(g, src_img, y, w, dil_k);
@@ -278,7 +291,6 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
     // get their Green accumulators cleared here.
     if (lane == 0) b.rowinfo[(size_t)s * g.H + y] = row_fg ? (int)runs_before : 0;
     const int last_start = chunk_carry;          // start x of the row's last run
-    long long *acc = b.acc + (size_t)s * g.Palloc * 3;
     for (int c0 = 0; c0 < g.words; c0 += 64) {
         const int w = c0 + lane;
         if (w >= g.words) continue;
@@ -294,6 +306,32 @@ __global__ __launch_bounds__(256) void k_rowscan(Geom g, const u64 *src_all, int
             parent[head] = (sx == 0 || sx == last_start) ? 0 : head;
             if ((F >> i) & 1ull) { acc[(size_t)head * 3] = 0; acc[(size_t)head * 3 + 1] = 0; acc[(size_t)head * 3 + 2] = 0; }
         }
+    }
+    }
+}
+
+template <bool ERODE, int WAVES, int ROWS>
+static void launch_rowscan_as(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
+                              int n_streams, int clear, hipStream_t st)
+{
+    const size_t lds = ERODE ? (size_t)(ROWS + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64) : 0;
+    hipLaunchKernelGGL((k_rowscan<ERODE, WAVES, ROWS>), dim3((g.H + ROWS - 1) / ROWS, n_streams), dim3(64 * WAVES), lds, st, g,
+                       src_bits, ERODE ? ero_k : 0, dil_k, b, first_stream, clear);
+}
+// shape: kRowscan4x4 (four waves a workgroup, a row each), kRowscan1xN (one wave a workgroup, N rows in turn)
+static void launch_rowscan(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
+                           int n_streams, int clear, hipStream_t st, int shape)
+{
+    const bool e = ero_k > 1;
+    switch (shape) {
+    case kRowscan1x4: e ? launch_rowscan_as<true, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
+                        : launch_rowscan_as<false, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
+    case kRowscan1x2: e ? launch_rowscan_as<true, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
+                        : launch_rowscan_as<false, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
+    case kRowscan1x1: e ? launch_rowscan_as<true, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
+                        : launch_rowscan_as<false, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
+    default:          e ? launch_rowscan_as<true, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
+                        : launch_rowscan_as<false, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
     }
 }
 
@@ -743,7 +781,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
         if (wait_failed) {
             if (t == 0) {
                 b.lds_ok[s] = 0u;
-                if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; results[s] = r; }
+                if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; r.path = kPathTimeout; results[s] = r; }
             }
             return;
         }
@@ -1143,17 +1181,12 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k)
 }
 
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode)
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode, int rowscan_shape)
 {
     const bool lds_able = g.H > 2 && g.H <= 16383 && g.W <= 16383;
     if (mode == kBlobSpec && !lds_able) mode = kBlobFull;
     const int clear = mode == kBlobGlobal || !lds_able;          // nobody else resets lds_ok then
-    if (ero_k > 1)
-        hipLaunchKernelGGL(k_rowscan<true>, dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
-                           st, g, src_bits, ero_k, dil_k, b, first_stream, clear);
-    else
-        hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
-                           dil_k, b, first_stream, clear);
+    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, rowscan_shape);
     if (lds_able && mode != kBlobGlobal)
         hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, b, min_area, max_area, results, results,
                            first_stream, mode == kBlobSpec ? 1 : 0, 0u, 0u);
@@ -1176,14 +1209,9 @@ __global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned tic
     __hip_atomic_store(&ready[first_stream + threadIdx.x], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st)
+                           int n_streams, unsigned ticket, hipStream_t st, int rowscan_shape)
 {
-    if (ero_k > 1)
-        hipLaunchKernelGGL(k_rowscan<true>, dim3((g.H + 3) / 4, n_streams), dim3(256), rowscan_lds_bytes(g, dil_k),
-                           st, g, src_bits, ero_k, dil_k, b, first_stream, 0);
-    else
-        hipLaunchKernelGGL(k_rowscan<false>, dim3((g.H + 3) / 4, n_streams), dim3(256), 0, st, g, src_bits, 0,
-                           dil_k, b, first_stream, 0);
+    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, 0, st, rowscan_shape);
     for (int s0 = 0; s0 < n_streams; s0 += 1024)
         hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
                            first_stream + s0, ticket);

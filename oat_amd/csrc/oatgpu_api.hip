@@ -9,6 +9,7 @@
 #include "oatgpu_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cstdarg>
@@ -19,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 using namespace oatgpu;
 
@@ -101,7 +103,13 @@ struct oatgpu_ctx {
                                      // bound by the host's calls, and hipExtLaunchKernel costs more of those: one 1080p stream -3 %),
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
     size_t early_min_px = 4000000;   // pixels a step from which the early order is considered (measurement builds: OATGPU_EARLY_MIN_PX)
-    int k1_wg_force = 0;             // measurement builds (OATGPU_K1_WG=64|256): the per-pixel kernel's workgroup size whatever the path
+    int k1_wg_force = 0;             // oatgpu_set_k1_workgroup (64 | 256): the per-pixel kernel's workgroup size whatever the path
+    unsigned long long early_timeouts = 0;   // frames whose parked blob workgroup gave up waiting for its row scan (kWaitTicks):
+                                     // something serialises kernel dispatches -- the context then stops parking (early_off)
+    bool early_off = false;
+    int rowscan_shape = -1;          // -1: by path (one-wave workgroups beside a one-wave per-pixel launch); measurement builds: OATGPU_ROWSCAN_SHAPE=0..3
+    int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
+    bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
     unsigned bh_ticket[kNB] = {};
     unsigned early_frames = 0;       // frames that took the early path (their parity picks scratch set and row-scan stream)
@@ -408,6 +416,35 @@ static void free_all(oatgpu_ctx *c)
     delete c;
 }
 
+// Opening the device.  Several processes that open one freshly booted device in the same instant (the ranks of a job, the
+// components of a pipeline started by one script) can see the first runtime calls fail transiently -- no device yet, the
+// device busy being initialised by a sibling.  Bounded retry with back-off (50 ms doubling, ~1.5 s in all); an ordinal that
+// does not exist is not transient.  Retries are counted (oatgpu_device_open_retries) so that a caller can report them
+// instead of hiding them.
+static std::atomic<int> g_open_retries{0};
+static hipError_t open_device(int device, int *ndev)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        *ndev = 0;
+        e = hipGetDeviceCount(ndev);
+        if (e == hipSuccess && *ndev > 0) {
+            if (device < 0 || device >= *ndev) return hipErrorInvalidDevice;
+            e = hipSetDevice(device);
+            if (e == hipSuccess) e = hipFree(nullptr);             // forces the context into being here, not in the first hipMalloc
+            if (e == hipSuccess) return hipSuccess;
+        } else if (e == hipSuccess) {
+            e = hipErrorNoDevice;
+        }
+        (void)hipGetLastError();
+        if (attempt == 5) break;
+        g_open_retries++;
+        usleep(50000u << attempt);
+    }
+    return e;
+}
+extern "C" int oatgpu_device_open_retries(void) { return g_open_retries.load(); }
+
 extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
 {
     if (!cfg) { fail(nullptr, OATGPU_E_INVALID, "null config"); return nullptr; }
@@ -434,16 +471,14 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (check_detector(nullptr, *cfg) != OATGPU_OK) return nullptr;
 
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
-        fail(nullptr, OATGPU_E_NODEVICE, "no HIP device available");
-        return nullptr;
-    }
-    if (cfg->device < 0 || cfg->device >= ndev) {
+    const hipError_t oe = open_device(cfg->device, &ndev);
+    if (oe == hipErrorInvalidDevice && ndev > 0) {
         fail(nullptr, OATGPU_E_INVALID, "device %d out of range (have %d)", cfg->device, ndev);
         return nullptr;
     }
-    if (hipSetDevice(cfg->device) != hipSuccess) {
-        fail(nullptr, OATGPU_E_HIP, "hipSetDevice(%d) failed", cfg->device);
+    if (oe != hipSuccess) {
+        if (ndev < 1) fail(nullptr, OATGPU_E_NODEVICE, "no HIP device available");
+        else fail(nullptr, OATGPU_E_HIP, "hipSetDevice(%d) failed: %s", cfg->device, hipGetErrorString(oe));
         return nullptr;
     }
 
@@ -490,6 +525,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
+    if (const char *e = measure_env("OATGPU_ROWSCAN_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 3) c->rowscan_shape = v; }
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
 
@@ -655,6 +691,23 @@ extern "C" int oatgpu_set_early_blob(oatgpu_ctx *c, int32_t on)
     return OATGPU_OK;
 }
 
+extern "C" int oatgpu_set_k1_workgroup(oatgpu_ctx *c, int32_t threads)
+{
+    if (!c || (threads != 0 && threads != 64 && threads != 256)) return fail(c, OATGPU_E_INVALID, "k1 workgroup must be 0 (by path), 64 or 256");
+    c->k1_wg_force = threads;
+    return OATGPU_OK;
+}
+
+extern "C" int oatgpu_last_step_shape(const oatgpu_ctx *c, int32_t *k1_workgroup, int32_t *early_blob)
+{
+    if (!c) return OATGPU_E_INVALID;
+    if (k1_workgroup) *k1_workgroup = c->last_k1_wg;
+    if (early_blob) *early_blob = c->last_step_early ? 1 : 0;
+    return OATGPU_OK;
+}
+
+extern "C" int64_t oatgpu_early_blob_timeouts(const oatgpu_ctx *c) { return c ? (int64_t)c->early_timeouts : 0; }
+
 extern "C" int oatgpu_set_fusion(oatgpu_ctx *c, int32_t frames_per_launch)
 {
     if (!c) return OATGPU_E_INVALID;
@@ -770,8 +823,8 @@ static int stage_in(oatgpu_ctx *c, void *dst, const void *src, size_t bytes)
 static int finish_frame(oatgpu_ctx *c, uint8_t *out, const uint8_t *dev, size_t bytes)
 {
     if (c->deferred) {
-        c->defer_kind = 1; c->defer_dev = dev; c->defer_bytes = bytes;
         HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        c->defer_kind = 1; c->defer_dev = dev; c->defer_bytes = bytes;       // (only once the wait succeeded: a failed call owes no fetch)
         return OATGPU_OK;
     }
     HIPCHK(c, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -792,9 +845,9 @@ extern "C" int oatgpu_fetch_frame(oatgpu_ctx *c, uint8_t *out)
     if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->defer_kind != 1) return fail(c, OATGPU_E_INVALID, "no deferred frame is waiting");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->defer_kind = 0;
     HIPCHK(c, hipMemcpyAsync(out, c->defer_dev, c->defer_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->defer_kind = 0;                  // (cleared once the frame has arrived: a failed fetch can be repeated)
     return OATGPU_OK;
 }
 
@@ -1078,7 +1131,7 @@ static void apply_kalman(const ResultRec &r, oatgpu_position *o)
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
 // the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
 static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int n, int slot, hipStream_t st,
-                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1, int mode = kBlobFull)
+                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1, int mode = kBlobFull, int rowscan_shape = kRowscan4x4)
 {
     const Geom &g = c->g;
     const u64 *src = thr;
@@ -1095,7 +1148,7 @@ static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int
     c->last_morph = (dil || ero) ? bb.morph : src;
     c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st, mode);
+    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st, mode, rowscan_shape);
     HIPCHK(c, hipGetLastError());
     return OATGPU_OK;
 }
@@ -1119,8 +1172,8 @@ static int detect_single(oatgpu_ctx *c, int s, const uint8_t *in, int channels, 
     if (rc) return rc;
     c->last_q = 0;
     if (c->deferred) {                    // the frame has been read; the position stays with the device (oatgpu_fetch_position)
-        c->defer_kind = 2; c->defer_s = s;
         HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        c->defer_kind = 2; c->defer_s = s;
         return OATGPU_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1151,8 +1204,8 @@ extern "C" int oatgpu_detect_diff(oatgpu_ctx *c, int32_t s, const uint8_t *grey_
     if (rc) return rc;
     c->last_q = 0;
     if (c->deferred) {
-        c->defer_kind = 2; c->defer_s = s;
         HIPCHK(c, hipEventSynchronize(c->ev_h2d));
+        c->defer_kind = 2; c->defer_s = s;
         return OATGPU_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1174,8 +1227,8 @@ extern "C" int oatgpu_fetch_position(oatgpu_ctx *c, oatgpu_position *out)
     if (!c || !out) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->defer_kind != 2) return fail(c, OATGPU_E_INVALID, "no deferred position is waiting");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->defer_kind = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->defer_kind = 0;
     to_position(c->res_host[(size_t)c->ring_slots * c->cfg.n_streams + c->defer_s], out);
     return OATGPU_OK;
 }
@@ -1257,6 +1310,7 @@ extern "C" int oatgpu_track_stage(oatgpu_ctx *c, int32_t stream_ix, const uint8_
     if (stream_ix < 0 || stream_ix >= n) return fail(c, OATGPU_E_INVALID, "stream index %d out of range", stream_ix);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first (oatgpu_fetch_frame / oatgpu_fetch_position)");
     if (c->staged_count == 0) {
         if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
         { const int rc = ensure_host_ring(c); if (rc) return rc; }
@@ -1416,7 +1470,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
     // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
     const bool early_wanted = c->early_blob < 0 ? n <= 3 : c->early_blob != 0;        // (r06a / r06e: 2 x 1080p 64.8 k -> 70.3 k fps, 3 x: 69.3 k -> 72-74 k, 4 x: 73.0 k -> 65-72 k)
-    const bool early = early_wanted && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
+    const bool early = early_wanted && !c->early_off && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
                        c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= c->early_min_px;
     // Threads a K1 workgroup (kernels_mog.hip, k_mog_fused): one wave a workgroup keeps every wave slot filled (K1 -3.5 % on
     // an everyday 4K model, -5.5 % on a dense one) and starves the back half's workgroups of slots.  Taken where that
@@ -1424,6 +1478,11 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // (streaming-load launches: K1 is 5-10 x the back half, 4K 6 670 -> 7 110 fps, profiles/r05n_dense_wg64_ab.txt; a result
     // is then ready ~230 us later, one K1 launch, because the blob workgroup gets in when the launch drains).
     const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads) ? 64 : 256;
+    // ... and the row scan's workgroups follow: beside a per-pixel launch of one-wave workgroups a four-wave workgroup starves
+    // for four simultaneous slots (kernels_blob.hip, k_rowscan)
+    const int rs_shape = c->rowscan_shape >= 0 ? c->rowscan_shape : (k1_wg == 64 ? kRowscan1x2 : kRowscan4x4);
+    c->last_k1_wg = k1_wg;
+    c->last_step_early = early;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
     // a second marker packet between two K1s on stream A)
     hipEvent_t k1_done = nullptr;
@@ -1508,7 +1567,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->last_fin = bb.fin;
             unsigned ticket = ++c->bh_ticket[q];
             if (!ticket) ticket = ++c->bh_ticket[q];
-            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
+            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R, rs_shape);
             bbs[i] = bb; res[i] = c->res_dev + (size_t)slot * n; tk[i] = ticket;
             c->slot_spec[slot] = 1;
             c->slot_q[slot] = 2;                         // a repair redoes the frame in scratch set 2 ...
@@ -1562,7 +1621,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->slot_spec[slot] = mode == kBlobSpec;
             c->slot_q[slot] = (char)q;
             c->slot_st[slot] = (char)q;
-            int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode);
+            int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode, rs_shape);
             if (rc) return rc;
         }
         if (c->kal_on) {
@@ -1586,8 +1645,18 @@ static int flush_pending(oatgpu_ctx *c)
 {
     if (!c->pend_valid) return OATGPU_OK;
     c->pend_valid = false;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    return launch_jobs(c, &c->pend, 1);
+    int rc = hipSetDevice(c->cfg.device) == hipSuccess ? OATGPU_OK : fail(c, OATGPU_E_HIP, "hipSetDevice(%d) failed", c->cfg.device);
+    if (!rc) rc = launch_jobs(c, &c->pend, 1);
+    if (rc) {
+        // the same rule as in enqueue_frames: mog_begin has advanced the frame counts and the rate schedule, the model may
+        // have moved -- fatal for the context.  The registered frame is no longer outstanding: without this a later collect
+        // would find its ring event as an earlier frame left it and hand out that frame's record as this one's.
+        c->broken = true;
+        c->enq_total--;
+        c->ring_count--;
+        c->err += " (the frame registered by the previous enqueue was dropped)";
+    }
+    return rc;
 }
 
 static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipEvent_t frames_ready)
@@ -1596,6 +1665,9 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
     // (a set being staged owns the next ring slot: nothing else may be enqueued until oatgpu_track_enqueue_staged took it)
     if (c->staged_count) return fail(c, OATGPU_E_INVALID, "a frame set is being staged (oatgpu_track_stage): finish it with oatgpu_track_enqueue_staged");
     if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
+    // (a deferred detector's kernels may still be running on stream A with threshold slot 0 and scratch set 0: the pipelined
+    // path would write both from its own streams)
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first (oatgpu_fetch_frame / oatgpu_fetch_position)");
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     oatgpu_ctx::FrameJob cur;
@@ -1641,11 +1713,29 @@ static bool slot_needs_global(const oatgpu_ctx *c, int slot)
     for (int s = 0; s < c->cfg.n_streams; ++s) if (r[s].valid == kNeedsGlobal) return true;
     return false;
 }
+// ... and did its parked workgroup give up WAITING (path == kPathTimeout) rather than find the frame too busy?
+static bool slot_timed_out(const oatgpu_ctx *c, int slot)
+{
+    const ResultRec *r = c->res_host + (size_t)slot * c->cfg.n_streams;
+    for (int s = 0; s < c->cfg.n_streams; ++s) if (r[s].valid == kNeedsGlobal && r[s].path == kPathTimeout) return true;
+    return false;
+}
 
 // ... on the frame's scratch set's stream, behind whatever later frame that is busy with; the slot's ring event is
 // recorded again behind them.  Not waited for here.
 static int launch_repair(oatgpu_ctx *c, int slot)
 {
+    if (slot_timed_out(c, slot)) {
+        // The blob workgroup was resident and its row scan never ran beside it: a tool serialises kernel dispatches (a
+        // counter-collecting profiler, a debug layer) or too many contexts share the hardware queues.  Correct either way
+        // (the global kernels redo the frame), but every such step costs 100 ms: stop parking for this context and say so.
+        c->early_timeouts++;
+        if (!c->early_off) {
+            c->early_off = true;
+            g_last_error = c->err = "early blob dispatch switched off for this context: a parked blob workgroup waited 100 ms for a row "
+                                    "scan that was not dispatched beside it (kernel dispatches are being serialised); results are unaffected";
+        }
+    }
     const int q = c->slot_q[slot];
     hipStream_t B = c->serial ? c->stream : c->stream_b[(int)c->slot_st[slot]];
     c->b_used[(int)c->slot_st[slot]] = true;
@@ -1782,8 +1872,8 @@ extern "C" int oatgpu_track_ready(oatgpu_ctx *c)
     return 1;
 }
 
-extern "C" int oatgpu_track_sequence_dev_timed(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
-                                               oatgpu_position *out, double *done_s)
+static int sequence_dev(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr, oatgpu_position *out,
+                        double *done_s, double *enq_s)
 {
     if (!c || !frames_dev || !out || n_frames < 0) return fail(c, OATGPU_E_INVALID, "null argument");
     if (c->ring_count) return fail(c, OATGPU_E_INVALID, "track_sequence while enqueued results are outstanding");
@@ -1799,6 +1889,7 @@ extern "C" int oatgpu_track_sequence_dev_timed(oatgpu_ctx *c, const void *const 
     c->in_sequence = true;               // every frame of the sequence is in hand: pairing is safe (oatgpu_set_fusion)
     for (int t = 0; t < n_frames && !rc; ++t) {
         if (c->ring_count == c->cfg.ring_depth) rc = collect_one();
+        if (!rc && enq_s) enq_s[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!rc) rc = oatgpu_track_enqueue_dev(c, frames_dev[t], lr);
     }
     c->in_sequence = false;
@@ -1807,10 +1898,22 @@ extern "C" int oatgpu_track_sequence_dev_timed(oatgpu_ctx *c, const void *const 
     return rc;
 }
 
+extern "C" int oatgpu_track_sequence_dev_timed(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
+                                               oatgpu_position *out, double *done_s)
+{
+    return sequence_dev(c, frames_dev, n_frames, lr, out, done_s, nullptr);
+}
+
+extern "C" int oatgpu_track_sequence_dev_latency(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
+                                                 oatgpu_position *out, double *done_s, double *enq_s)
+{
+    return sequence_dev(c, frames_dev, n_frames, lr, out, done_s, enq_s);
+}
+
 extern "C" int oatgpu_track_sequence_dev(oatgpu_ctx *c, const void *const *frames_dev, int32_t n_frames, double lr,
                                          oatgpu_position *out)
 {
-    return oatgpu_track_sequence_dev_timed(c, frames_dev, n_frames, lr, out, nullptr);
+    return sequence_dev(c, frames_dev, n_frames, lr, out, nullptr, nullptr);
 }
 
 extern "C" int oatgpu_track_outstanding(const oatgpu_ctx *c) { return c ? c->ring_count : 0; }

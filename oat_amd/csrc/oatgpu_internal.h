@@ -123,9 +123,9 @@ void launch_mog_fused(const Geom &g, const MogLaunch &a, int first_stream, int n
 void launch_stream_read(const void *src, size_t n16, unsigned *sink, hipStream_t st);
 void launch_stream_copy(const void *src, void *dst, size_t n16, hipStream_t st);
 void launch_density_probe(const uint8_t *nmodes, size_t total, unsigned *out, hipStream_t st);   // out = {live modes, samples}
-void launch_nop(hipStream_t st);
+void launch_nop(hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
 // bytes from device-visible (page-locked, mapped) host memory to device memory by a kernel; both 16-byte aligned
-void launch_stage_copy(const void *src_dev_visible, void *dst, size_t bytes, hipStream_t st);   // one empty wave: calibrates what an event pair adds around a launch
+void launch_stage_copy(const void *src_dev_visible, void *dst, size_t bytes, hipStream_t st);
 void launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, size_t npx, hipStream_t st);
 // code 0: BGR -> GREY, 1: GREY -> BGR, 2: HSV -> BGR (Color.h:45-51); in/out 4-byte aligned
 void launch_cvt_color(int code, const uint8_t *in, uint8_t *out, size_t npx, hipStream_t st);
@@ -180,7 +180,8 @@ struct ResultRec {   // device-side result, one per stream per step
     int valid;
     // written by k_kalman when the position filter is on
     int kal_valid;
-    int path;            // who wrote the record: 1 = k_blob_lds, 0 = k_green_select (host: when to speculate, below)
+    int path;            // who wrote the record: 1 = k_blob_lds, 0 = k_green_select (host: when to speculate, below);
+                         // kPathTimeout beside valid == kNeedsGlobal: the parked k_blob_lds workgroup gave up waiting for its ticket
     double kx, ky, kvx, kvy;
 };
 
@@ -215,14 +216,18 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k);
 //                     the caller runs kBlobGlobal on the same threshold bits before it hands the result out;
 //       kBlobGlobal = row scan + k_merge + k_green_select.
 enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
+// workgroup shape of the row scan (kernels_blob.hip, k_rowscan): four waves with a row each, or ONE wave taking 4 / 2 / 1 rows
+enum { kRowscan4x4 = 0, kRowscan1x4 = 1, kRowscan1x2 = 2, kRowscan1x1 = 3 };
 constexpr int kNeedsGlobal = -2;
+constexpr int kPathTimeout = 2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull,
+                 int rowscan_shape = kRowscan4x4);
 // The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan with a one-lane kernel behind
 // it that publishes `ticket`, and everything behind the row scan, whose k_blob_lds workgroup may be dispatched long before
 // the row scan has run and waits for `ticket` on the device.  ticket != 0.
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st);
+                           int n_streams, unsigned ticket, hipStream_t st, int rowscan_shape = kRowscan4x4);
 // the blob workgroups of the nf (1 or 2) frames of a step in ONE launch (speculative mode): arrays of nf scratch sets,
 // result records and tickets
 void launch_blob_tail2(const Geom &g, const BlobBuffers *b, double min_area, double max_area, ResultRec *const *results,

@@ -93,9 +93,12 @@ class FrameScatterPipe:
     transfer with a stream-to-stream wait instead of blocking the host (without a consumer it synchronises the
     device's current stream, which serialises the overlap the pipe exists for).  Backend "nccl" (= RCCL) on the
     GPU box; the tests drive the same code over gloo.  Unmeasured on multi-GPU hardware so far (the builder has
-    one GPU at a time): the driver's SCALE run uses per-rank ingest, not this path."""
+    one GPU at a time); bench.py's N > 1 runs time it as their `scatter_ingest` leg beside the per-rank-ingest `value`.
 
-    def __init__(self, n_streams_total, frame_shape, device, src=0, group=None, depth=2, consumer=None):
+    via_host=True: the transport runs between page-locked HOST buffers and take() uploads the block -- for backends
+    that cannot send from device memory (gloo: the 2-rank smoke tests on one GPU).  Never the RCCL path."""
+
+    def __init__(self, n_streams_total, frame_shape, device, src=0, group=None, depth=2, consumer=None, via_host=False):
         self.total, self.shape, self.device, self.src, self.group = n_streams_total, tuple(frame_shape), device, src, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.per = -(-n_streams_total // self.world)
@@ -103,9 +106,14 @@ class FrameScatterPipe:
         self.depth = depth
         self.consumer = consumer
         self.buf = [torch.empty((self.per,) + self.shape, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.via_host = bool(via_host) and torch.device(device).type == "cuda"
+        self.xbuf = None
+        if self.via_host and self.rank != src:
+            self.xbuf = [torch.empty((self.per,) + self.shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.work = [None] * depth          # outstanding requests of the slot
         self.keep = [None] * depth          # root: the frame tensor being sent out of
         self.step_of = [None] * depth
+        self.bytes_per_peer = self.per * int(np.prod(self.shape))
 
     def post(self, t, frames_root=None):
         k = t % self.depth
@@ -117,18 +125,19 @@ class FrameScatterPipe:
         if self.rank == self.src:
             fr = frames_root if frames_root.device == self.buf[k].device else frames_root.to(self.device, non_blocking=True)
             assert fr.shape[0] == self.total and tuple(fr.shape[1:]) == self.shape
-            self.keep[k] = fr
+            out = fr.cpu() if (self.via_host and self.world > 1) else fr        # (host transport: one D2H of the whole set)
+            self.keep[k] = (fr, out)
             for peer in range(self.world):
                 blk = stream_partition(self.total, self.world, peer)
                 if not len(blk):
                     continue
-                chunk = fr[blk.start:blk.stop]
                 if peer == self.rank:
-                    self.buf[k][:len(blk)].copy_(chunk, non_blocking=True)
+                    self.buf[k][:len(blk)].copy_(fr[blk.start:blk.stop], non_blocking=True)
                 else:
-                    ops.append(dist.P2POp(dist.isend, chunk.contiguous(), peer, self.group))
+                    ops.append(dist.P2POp(dist.isend, out[blk.start:blk.stop].contiguous(), peer, self.group))
         elif len(self.mine):
-            ops.append(dist.P2POp(dist.irecv, self.buf[k][:len(self.mine)], self.src, self.group))
+            dst = self.xbuf[k] if self.via_host else self.buf[k]
+            ops.append(dist.P2POp(dist.irecv, dst[:len(self.mine)], self.src, self.group))
         self.work[k] = dist.batch_isend_irecv(ops) if ops else []
         self.step_of[k] = t
 
@@ -138,6 +147,8 @@ class FrameScatterPipe:
             raise RuntimeError(f"step {t} was not posted (slot holds {self.step_of[k]})")
         for w in self.work[k]:
             w.wait()
+        if self.xbuf is not None and len(self.mine):
+            self.buf[k][:len(self.mine)].copy_(self.xbuf[k][:len(self.mine)], non_blocking=True)
         if self.buf[k].is_cuda:
             cur = torch.cuda.current_stream(self.buf[k].device)
             if self.consumer is not None and self.consumer.get_stream():

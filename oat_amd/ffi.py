@@ -6,8 +6,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    """The product library; OATGPU_LIB overrides the path (A/B builds of kernel variants)."""
-    return os.environ.get("OATGPU_LIB") or os.path.join(_HERE, "lib", "liboatgpu.so")
+    """The product library.  Only with OATGPU_MEASURE_PY=1 in the environment does OATGPU_LIB redirect the binding to
+    another build (the A/B tools under tools/ set both): nothing else in the environment changes what is loaded."""
+    if os.environ.get("OATGPU_MEASURE_PY") == "1" and os.environ.get("OATGPU_LIB"):
+        return os.environ["OATGPU_LIB"]
+    return os.path.join(_HERE, "lib", "liboatgpu.so")
 
 
 class OatGpuError(RuntimeError):
@@ -53,7 +56,7 @@ class Traffic(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 7          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 8          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -68,6 +71,7 @@ SIGNATURES = {
     "oatgpu_destroy": (None, [_ctx]),
     "oatgpu_last_error": (C.c_char_p, [_ctx]),
     "oatgpu_device_count": (C.c_int, []),
+    "oatgpu_device_open_retries": (C.c_int, []),
     "oatgpu_device_numa_node": (C.c_int, [C.c_int32]),
     "oatgpu_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "oatgpu_host_unregister": (C.c_int, [C.c_void_p]),
@@ -92,6 +96,9 @@ SIGNATURES = {
     "oatgpu_fetch_frame": (C.c_int, [_ctx, _u8p]),
     "oatgpu_fetch_position": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_set_early_blob": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_early_blob_timeouts": (C.c_int64, [_ctx]),
+    "oatgpu_set_k1_workgroup": (C.c_int, [_ctx, C.c_int32]),
+    "oatgpu_last_step_shape": (C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oatgpu_set_homography": (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_double)]),
     "oatgpu_detect_hsv": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
     "oatgpu_detect_thresh": (C.c_int, [_ctx, C.c_int32, _u8p, C.POINTER(Position)]),
@@ -103,6 +110,8 @@ SIGNATURES = {
     "oatgpu_track_sequence_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position)]),
     "oatgpu_track_sequence_dev_timed": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position),
                                                   C.POINTER(C.c_double)]),
+    "oatgpu_track_sequence_dev_latency": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.POINTER(Position),
+                                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oatgpu_track_collect": (C.c_int, [_ctx, C.POINTER(Position)]),
     "oatgpu_track_outstanding": (C.c_int, [_ctx]),
     "oatgpu_track_input_consumed": (C.c_int, [_ctx]),

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_default_config(lib):
     from oat_amd import ffi
-    assert lib.oatgpu_abi_version() == ffi.ABI_VERSION == 7
+    assert lib.oatgpu_abi_version() == ffi.ABI_VERSION == 8
     cfg = ffi.Config()
     assert lib.oatgpu_default_config(C.byref(cfg)) == 0
     # cv::createBackgroundSubtractorMOG2() defaults + HSVDetector.h:77-94
@@ -84,3 +84,15 @@ def test_hsv_table_integer_formula_equals_cvround():
                 for _ in range(abs(ulps)):
                     rr = np.nextafter(rr, np.float32(np.inf if ulps > 0 else 0), dtype=np.float32)
                 assert int(np.floor(np.float32(2 * n + i) * rr)) == q, (i, n, ulps)
+
+
+def test_oatgpu_lib_redirect_needs_the_measure_switch(monkeypatch):
+    """OATGPU_LIB alone must not change what the Python binding loads: only together with
+    OATGPU_MEASURE_PY=1, which the A/B tools under tools/ set."""
+    from oat_amd import ffi
+    product = os.path.join(os.path.dirname(os.path.abspath(ffi.__file__)), "lib", "liboatgpu.so")
+    monkeypatch.setenv("OATGPU_LIB", "/tmp/some_other_build.so")
+    monkeypatch.delenv("OATGPU_MEASURE_PY", raising=False)
+    assert ffi.lib_path() == product
+    monkeypatch.setenv("OATGPU_MEASURE_PY", "1")
+    assert ffi.lib_path() == "/tmp/some_other_build.so"

@@ -10,9 +10,9 @@ bash tools/ab.sh $out "$variants" "--workload 4k1 --steps 1000;--workload 1080p1
 for v in $variants; do
   lib=$R/oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=$R/oat_amd/lib/liboatgpu.so
   echo "== ktrace 4k1 pipelined, variant '$v'" | tee -a $out/ab.txt
-  OATGPU_LIB=$lib bash tools/ktrace.sh $out/kt_$v.md --workload 4k1 --steps 1000 --warmup 40 | grep -E "kernel \||k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib bash tools/ktrace.sh $out/kt_$v.md --workload 4k1 --steps 1000 --warmup 40 | grep -E "kernel \||k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
   echo "== ktrace 1080p1 pipelined, variant '$v'" | tee -a $out/ab.txt
-  OATGPU_LIB=$lib bash tools/ktrace.sh $out/kt1080_$v.md --workload 1080p1 --steps 1000 --warmup 40 | grep -E "k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib bash tools/ktrace.sh $out/kt1080_$v.md --workload 1080p1 --steps 1000 --warmup 40 | grep -E "k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
   echo "== synchronous single-frame steps, variant '$v'" | tee -a $out/ab.txt
-  OATGPU_LIB=$lib bash tools/ktrace_latency.sh $out/lat_$v.md | grep -E "per synchronous|k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib bash tools/ktrace_latency.sh $out/lat_$v.md | grep -E "per synchronous|k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
 done

@@ -11,7 +11,7 @@ echo "|---|---|---|---|---|---|"
 for n in 1 2 3 4 5 base; do
   lib=$R/oat_amd/lib/liboatgpu_cut$n.so; [ $n = base ] && lib=$R/oat_amd/lib/liboatgpu_base.so
   rm -rf /tmp/cutp
-  OATGPU_LIB=$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d /tmp/cutp -o r -- python $R/tools/cut_profile.py run "$@" /tmp/cut_state > /dev/null 2> /tmp/cutp.err || tail -2 /tmp/cutp.err
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d /tmp/cutp -o r -- python $R/tools/cut_profile.py run "$@" /tmp/cut_state > /dev/null 2> /tmp/cutp.err || tail -2 /tmp/cutp.err
   db=$(find /tmp/cutp -name "*.db" | head -1)
   python - $db $n <<'PY'
 import sqlite3, sys

@@ -18,7 +18,7 @@ for r in $(seq $reps); do
         S) args="--workload 4k1 --fusion 2 --steps 1000 --quick --check-steps 16";;
       esac
       f=$out/${v}_${lds:-0}_${leg}_$r
-      OATGPU_K1_LDS=$lds OATGPU_LIB=$PWD/$lib python bench.py $args > $f.json 2> $f.log
+      OATGPU_K1_LDS=$lds OATGPU_MEASURE_PY=1 OATGPU_LIB=$PWD/$lib python bench.py $args --detail-out $f.json > $f.line 2> $f.log
       python - $f.json "$c" $leg <<'PY'
 import json, sys
 try:

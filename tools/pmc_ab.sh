@@ -3,7 +3,7 @@
 out=$1; mkdir -p $out
 for v in $2; do
   lib=oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
-  OATGPU_LIB=$PWD/$lib python bench.py --no-extra --no-cpu-baseline --check-steps 16 > $out/$v.json 2> $out/$v.log
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$PWD/$lib python bench.py --no-extra --no-cpu-baseline --check-steps 16 --detail-out $out/$v.json > $out/$v.line 2> $out/$v.log
   python - $out/$v.json $v <<'PY'
 import json, sys
 j = json.load(open(sys.argv[1])); r = j["roofline"]; b = r["benched_workload"]
