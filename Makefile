@@ -41,11 +41,15 @@ clean:
 
 .PHONY: all oracle host tools clean
 
-# A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> oat_amd/lib/liboatgpu_px2.so
+# A/B variant builds: make variant NAME=px2 DEFS="-DOATGPU_PX=2"  -> build/variants/liboatgpu_px2.so
 # Only these builds (-DOATGPU_MEASURE) read the OATGPU_EXPT / SERIAL / NB / ... measurement switches from the
-# environment; the product library ignores them.
+# environment; the product library ignores them.  They live under build/ (git-ignored, but they travel to the GPU box):
+# oat_amd/lib/ holds the product library and nothing else, and the Python binding loads another library only with
+# OATGPU_MEASURE_PY=1 OATGPU_LIB=<path> (oat_amd/ffi.py; the tools/*.sh A/B scripts set both).
 variant:
-	@mkdir -p build/$(NAME) oat_amd/lib
+	@mkdir -p build/$(NAME) build/variants
 	for f in kernels_mog kernels_blob kernels_kalman oatgpu_api; do $(HIPCC) $(HIPFLAGS) -DOATGPU_MEASURE $(DEFS) -c $(CSRC)/$$f.hip -o build/$(NAME)/$$f.o || exit 1; done
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o oat_amd/lib/liboatgpu_$(NAME).so build/$(NAME)/*.o
-.PHONY: variant
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/liboatgpu_$(NAME).so build/$(NAME)/*.o
+clean-variants:
+	rm -rf build/variants oat_amd/lib/liboatgpu_*.so
+.PHONY: variant clean-variants

@@ -169,11 +169,30 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 //           (k_mog_fused, WG = 64) a four-wave workgroup waits for four free wave slots on ONE compute unit at the same
 //           instant while every slot that frees up is refilled at once by the other queue: 12 us alone became 65-76 us
 //           beside it (profiles/r05q_kernel_stats_4k1_sparse.md).  A one-wave workgroup takes any slot, like its rival.
+#ifdef OATGPU_RS_TIMING             // measurement builds only (make variant DEFS=-DOATGPU_RS_TIMING, tools/rowscan_probe.py)
+constexpr unsigned kRsTkRing = 1u << 16;
+__device__ long long g_rs_tk[kRsTkRing * 4u];       // {first instruction, last instruction, workgroup, tag} of a workgroup (100 MHz wall clock)
+__device__ unsigned g_rs_tk_n;
+extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(long long *out, int max_rows)
+{
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rs_tk_n), sizeof n) != hipSuccess) return -1;
+    const unsigned rows = n < kRsTkRing ? n : kRsTkRing;
+    const unsigned take = rows < (unsigned)max_rows ? rows : (unsigned)max_rows;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_tk), (size_t)take * 4u * sizeof(long long)) != hipSuccess) return -1;
+    return (int)take;
+}
+#endif
+
 template <bool ERODE, int WAVES, int ROWS>
 __global__ __launch_bounds__(64 * WAVES) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                        int first_stream, int clear_lds_ok)
+                                                        int first_stream, int clear_lds_ok, unsigned tag)
 {
     extern __shared__ u64 er[];
+#ifdef OATGPU_RS_TIMING
+    const long long rs_t0 = wall_clock64();
+#endif
     constexpr int NT = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -308,30 +327,44 @@ __global__ __launch_bounds__(64 * WAVES) void k_rowscan(Geom g, const u64 *src_a
         }
     }
     }
+#ifdef OATGPU_RS_TIMING
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        const unsigned slot = atomicAdd(&g_rs_tk_n, 1u) & (kRsTkRing - 1u);
+        g_rs_tk[slot * 4u] = rs_t0; g_rs_tk[slot * 4u + 1] = wall_clock64(); g_rs_tk[slot * 4u + 2] = blockIdx.x; g_rs_tk[slot * 4u + 3] = tag;
+    }
+#else
+    (void)tag;
+#endif
 }
 
 template <bool ERODE, int WAVES, int ROWS>
 static void launch_rowscan_as(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
-                              int n_streams, int clear, hipStream_t st)
+                              int n_streams, int clear, hipStream_t st, unsigned tag)
 {
     const size_t lds = ERODE ? (size_t)(ROWS + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64) : 0;
     hipLaunchKernelGGL((k_rowscan<ERODE, WAVES, ROWS>), dim3((g.H + ROWS - 1) / ROWS, n_streams), dim3(64 * WAVES), lds, st, g,
-                       src_bits, ERODE ? ero_k : 0, dil_k, b, first_stream, clear);
+                       src_bits, ERODE ? ero_k : 0, dil_k, b, first_stream, clear, tag);
 }
 // shape: kRowscan4x4 (four waves a workgroup, a row each), kRowscan1xN (one wave a workgroup, N rows in turn)
 static void launch_rowscan(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
-                           int n_streams, int clear, hipStream_t st, int shape)
+                           int n_streams, int clear, hipStream_t st, int shape, unsigned tag = 0u)
 {
     const bool e = ero_k > 1;
     switch (shape) {
-    case kRowscan1x4: e ? launch_rowscan_as<true, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
-                        : launch_rowscan_as<false, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
-    case kRowscan1x2: e ? launch_rowscan_as<true, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
-                        : launch_rowscan_as<false, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
-    case kRowscan1x1: e ? launch_rowscan_as<true, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
-                        : launch_rowscan_as<false, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
-    default:          e ? launch_rowscan_as<true, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st)
-                        : launch_rowscan_as<false, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st); break;
+    case kRowscan1x4: e ? launch_rowscan_as<true, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    case kRowscan1x2: e ? launch_rowscan_as<true, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    case kRowscan1x1: e ? launch_rowscan_as<true, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    case kRowscan8x8: e ? launch_rowscan_as<true, 8, 8>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 8, 8>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    case kRowscan16x16: e ? launch_rowscan_as<true, 16, 16>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                          : launch_rowscan_as<false, 16, 16>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    case kRowscan2x2: e ? launch_rowscan_as<true, 2, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 2, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
+    default:          e ? launch_rowscan_as<true, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
+                        : launch_rowscan_as<false, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
     }
 }
 
@@ -651,9 +684,6 @@ __global__ __launch_bounds__(kGreenBlock) void k_green_select(Geom g, BlobBuffer
 // Falls back (lds_ok = 0: k_merge + k_green_select take the frame) when the frame has more than kLdsRows dirty rows,
 // kLdsRuns runs or kLdsRoots foreground components.
 constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768;      // 58 KB of LDS
-#ifndef OATGPU_LDS_BLOCK
-#define OATGPU_LDS_BLOCK 1024
-#endif
 // Threads of the one workgroup.  Beside the per-pixel kernel a launch of this kernel lasts 81-96 us at 4K in a kernel
 // trace, against 21-27 us alone.  What the difference is (r03, tools/lds_phase_probe.py with a -DOATGPU_LDS_TIMING build:
 // the kernel stamps the 100 MHz wall clock between its phases, profiles/r03j_backhalf_slot_wait.txt): the workgroup
@@ -669,11 +699,8 @@ constexpr int kLdsRows = 1024, kLdsRuns = 3072, kLdsRoots = 768;      // 58 KB o
 // kernel to 72 / 72 / 38 us and costs the per-pixel kernel 10 % whatever the number (107 -> 118 us per two-frame 4K
 // launch, 17.5 k -> 15.9 k fps): not adopted.  A camera-bound pipeline never sees the wait: no later frame's
 // per-pixel kernel is running when a frame's back half starts.
-constexpr int kLdsBlock = OATGPU_LDS_BLOCK;
-#ifndef OATGPU_LDS_TRIP
-#define OATGPU_LDS_TRIP 8
-#endif
-constexpr int kLdsTrip = OATGPU_LDS_TRIP;      // words of the run-start image a thread has in flight per trip of phase B
+constexpr int kLdsBlock = 1024;
+constexpr int kLdsTrip = 8;      // words of the run-start image a thread has in flight per trip of phase B
 
 #ifdef OATGPU_LDS_TIMING           // measurement builds only (make variant DEFS=-DOATGPU_LDS_TIMING, tools/lds_phase_probe.py)
 constexpr unsigned kLdsTkRing = 4096u;
@@ -1211,7 +1238,7 @@ __global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned tic
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
                            int n_streams, unsigned ticket, hipStream_t st, int rowscan_shape)
 {
-    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, 0, st, rowscan_shape);
+    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, 0, st, rowscan_shape, ticket);
     for (int s0 = 0; s0 < n_streams; s0 += 1024)
         hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
                            first_stream + s0, ticket);

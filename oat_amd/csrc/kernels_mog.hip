@@ -60,11 +60,7 @@ struct PxModel<3, true> {
     float w[kMaxMix];
     f32x4 r[kMaxMix];            // {variance, mean[0..2]}
 };
-#ifdef OATGPU_NO_TUPLE_RECORDS       // (make variant DEFS=-DOATGPU_NO_TUPLE_RECORDS: the A/B build)
-#define OATGPU_TUP(CH, NTLD) false
-#else
 #define OATGPU_TUP(CH, NTLD) ((CH) == 3 && !(NTLD))
-#endif
 template <int CH> __device__ __forceinline__ float rv(const PxModel<CH, false> &s, int k) { return s.v[k]; }
 template <int CH> __device__ __forceinline__ float rv(const PxModel<CH, true> &s, int k) { return s.r[k][0]; }
 template <int CH> __device__ __forceinline__ void set_rv(PxModel<CH, false> &s, int k, float x) { s.v[k] = x; }
@@ -93,18 +89,10 @@ __device__ __forceinline__ void swap_up(PxModel<CH, false> &s, int i, unsigned &
     // two-frame instantiation NEEDED this form to be right; it only moved the register allocation away from st_rec's
     // wide-store hazard -- DESIGN.md 3b.  The asm operands pin registers, which is why the GREY two-frame
     // instantiations are compiled for 7 waves/SIMD: at 8 they went into scratch.)
-#ifndef OATGPU_NO_VSWAP          // (make variant NAME=noswap DEFS=-DOATGPU_NO_VSWAP: the A/B build)
     asm volatile("v_swap_b32 %0, %1" : "+v"(s.w[i]), "+v"(s.w[i - 1]));
     asm volatile("v_swap_b32 %0, %1" : "+v"(s.v[i]), "+v"(s.v[i - 1]));
 #pragma unroll
     for (int c = 0; c < CH; ++c) asm volatile("v_swap_b32 %0, %1" : "+v"(s.m[i][c]), "+v"(s.m[i - 1][c]));
-#else
-    float t;
-    t = s.w[i]; s.w[i] = s.w[i - 1]; s.w[i - 1] = t;
-    t = s.v[i]; s.v[i] = s.v[i - 1]; s.v[i - 1] = t;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) { t = s.m[i][c]; s.m[i][c] = s.m[i - 1][c]; s.m[i - 1][c] = t; }
-#endif
 }
 template <int CH>
 __device__ __forceinline__ void swap_up(PxModel<CH, true> &s, int i, unsigned &dvm)
@@ -180,9 +168,7 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 // two-frame 4K launch at rate 0 84.9 -> 79.9 us, 22.2 k -> 23.4 k fps, profiles/r05t_frozen_identity_update_ab.txt).
                 // A lane whose weight is anything else takes the update.
                 bool upd = true;
-#ifndef OATGPU_NO_FROZEN_NOOP         // (make variant DEFS=-DOATGPU_NO_FROZEN_NOOP: the A/B build)
                 if (FROZEN == 1) upd = !__builtin_amdgcn_classf(weight, 0x100 | 0x80);       // not (+normal | +denormal)
-#endif
                 if (upd) {
                 const float k = rate_over_weight<FROZEN>(alphaT, weight);
                 const float o0 = rm<0>(s, MODE), o1 = CH == 3 ? rm<1>(s, MODE) : 0.f, o2 = CH == 3 ? rm<2>(s, MODE) : 0.f;
@@ -190,10 +176,14 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 set_rm<0>(s, MODE, n0);
                 if (CH == 3) { set_rm<1>(s, MODE, n1); set_rm<2>(s, MODE, n2); }
                 float varnew = var + k * (dist2 - var);
-                // MAX(varnew, varMin) then MIN(.., varMax) of the reference's macros -- as v_max_f32 / v_min_f32: with a
-                // NaN on the left the macro yields the bound, and so does the instruction (the bounds are never NaN)
-                varnew = __builtin_fmaxf(varnew, P.varMin);
-                varnew = __builtin_fminf(varnew, P.varMax);
+                // MAX(varnew, varMin) then MIN(.., varMax) with OpenCV's macros -- MAX(a,b) ((a) < (b) ? (b) : (a)),
+                // MIN(a,b) ((a) > (b) ? (b) : (a)): a comparison with a NaN is false, so a NaN variance (k = 0 / 0: a pruned slot
+                // matched again at learning rate 0) STAYS NaN.  v_max_f32 / v_min_f32 would return the bound instead (IEEE maxNum);
+                // gfx950's v_maximum3_f32 / v_minimum3_f32 propagate the NaN like the macros, at the same one instruction each.
+                // [OCV-mem]: the macro definitions are recalled, not read (no OpenCV here) -- tests/test_opencv_crosscheck.py
+                // test_mog2_nan_variance_clamp settles it where a cv2 exists; the oracle (oracle/mog2.c) follows the same reading.
+                varnew = __builtin_elementwise_maximum(varnew, P.varMin);
+                varnew = __builtin_elementwise_minimum(varnew, P.varMax);
                 set_rv(s, MODE, varnew);
                 // The record goes back to memory when it was written.  At learning rate 0 -- Oat's default, a frozen model --
                 // k is 0 and the update leaves every bit as it was (unless the variance sat outside its clamp or the model
@@ -460,15 +450,9 @@ struct Audit {
 // Waves per SIMD the two-frame instantiations are compiled for.  The streaming-load one (dense models) needs 72
 // registers to stay out of scratch: at 8 waves (64 registers, 20-40 bytes of scratch a lane) the dense 4K launch took
 // 343-351 us, at 7 waves 285-293 us, at 6 waves 303-308 us (gpurun_out/ab_nt.txt).
-#ifndef OATGPU_AUDIT_WAVES
 #define OATGPU_AUDIT_WAVES 4
-#endif
-#ifndef OATGPU_NT2_WAVES
 #define OATGPU_NT2_WAVES 7
-#endif
-#ifndef OATGPU_F2_WAVES
 #define OATGPU_F2_WAVES 8
-#endif
 // ... and the one-frame instantiations (r04, profiles/r04a_k1_one_frame_waves_spills_ab.txt, r04c_k1_dense_one_vs_two_frames_ab.txt).
 // Streaming loads (dense models): compiled for "7 waves" the instantiation has 90 scalar registers and NO spill (13 at 8) at
 // the same 60 vector registers -- the hardware still runs it 8 waves a SIMD (96 scalar registers a wave is what 8 waves
@@ -477,12 +461,8 @@ struct Audit {
 // occupancy is not what separates it from its two-frame sibling (286-294 us on that second box) either.
 // Default policy (everyday models): compiled for 7 waves the 93 + 6 scalar registers DO cost the eighth wave (112 allocated):
 // 76.2 -> 81.5 us at 4K, and 88.3 us at 6 waves -- the everyday launch lives on its occupancy; left at 8 with its 5 spills.
-#ifndef OATGPU_NT1_WAVES
 #define OATGPU_NT1_WAVES 7
-#endif
-#ifndef OATGPU_F1_WAVES
 #define OATGPU_F1_WAVES 8
-#endif
 template <int CH, bool AUDIT, bool NTLD, int NF>
 constexpr int k1_waves()
 {
@@ -539,11 +519,7 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
     Audit<AUDIT> au;
     // (late arguments: the product two-frame BGR instantiation only -- the others are not bound by their instruction count
     // or were left as compiled)
-#ifdef OATGPU_LATE_NTLD              // (make variant DEFS=-DOATGPU_LATE_NTLD: the A/B build)
-    constexpr bool kLate = !AUDIT && CH == 3;
-#else
     constexpr bool kLate = !NTLD && !AUDIT && CH == 3;
-#endif
     KArgs ka = (KArgs)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + kMogLaunchArgOffset);
     // Nothing here spends vector instructions on what the scalar unit or the address path can do (the kernel was
     // 79 % VALU-busy at 370 VALU instructions per wave before, profiles/r02_k1_sq_counters_before.md): every plane
@@ -585,13 +561,8 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
 // 16 x 1080p 464.6 -> 425.3 us.  On a dense model (NTLD) it is the other way round, as r02 found: mode 0 default, slots 1..4
 // streaming (mode 0 streaming there: 302.9 -> 305.6 us).  Loads only: worse (114.4 us); stores of slots 1..4 with the default
 // policy: worse.
-#ifdef OATGPU_M0_DEFAULT_POLICY      // (make variant DEFS=-DOATGPU_M0_DEFAULT_POLICY: the A/B build)
-#define OATGPU_M0_LD 0
-#define OATGPU_M0_ST 0
-#else
 #define OATGPU_M0_LD ((CH == 3 && !NTLD) ? 2 : 0)
 #define OATGPU_M0_ST ((CH == 3 && !NTLD) ? 2 : 0)
-#endif
 #define OATGPU_K_ST 2
 // (the frames' bytes and the counter bytes with the streaming policy: no change either way, profiles/r03b_k1_ab.txt section 12)
 #define LDW(k) __builtin_bit_cast(float, (k) == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), OATGPU_M0_LD) : NTLD ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 2) : __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_w, SW(k), 0))
@@ -612,15 +583,11 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
     auto ld_rec = [&](int k) {                                      // {variance, mean[CH]} of mode k
         const char *rp = (const char *)(sbase + mog_vm_off(g.Palloc, CH, k)) + voff_r;
         if constexpr (TUP) {
-#ifdef OATGPU_GLOBAL_REC_LOADS       // (A/B: the `uniform pointer + lane offset` form, two 64-bit address instructions per load)
-            pm.r[k] = *(const f32x4 *)rp;
-#else
             // through the buffer resource: address = lane offset (a register the stores use anyway) + a scalar -- no vector
             // instruction per load (r02 measured this form slower in the scalar-register kernel, which was not yet bound by
             // its instruction count)
             if (k == 0) pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), OATGPU_M0_LD));
             else pm.r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_r, SR(k), 0));
-#endif
         } else if constexpr (CH == 3) {
             if (NTLD && k >= 1) {
                 // (through the buffer resource as well: 292-298 us against 293-301 us on the dense 4K launch -- no change)
@@ -766,11 +733,7 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
     // three no longer, but two.
     // (Not in the streaming-load instantiations: on a dense model every lane is full in frame 1 anyway.)
     bool want2 = false;
-#ifdef OATGPU_NO_EARLY2              // (make variant DEFS=-DOATGPU_NO_EARLY2: the A/B build)
-    constexpr bool kEarly2 = false;
-#else
     constexpr bool kEarly2 = NF == 2 && !NTLD;
-#endif
     if (kEarly2) {
         const float z0 = (float)(px2 & 255u), z1 = (float)((px2 >> 8) & 255u), z2 = (float)(px2 >> 16);
         const float var = rv(pm, 0);

@@ -525,7 +525,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     }
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
-    if (const char *e = measure_env("OATGPU_ROWSCAN_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 3) c->rowscan_shape = v; }
+    if (const char *e = measure_env("OATGPU_ROWSCAN_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 6) c->rowscan_shape = v; }
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
 
@@ -1480,7 +1480,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads) ? 64 : 256;
     // ... and the row scan's workgroups follow: beside a per-pixel launch of one-wave workgroups a four-wave workgroup starves
     // for four simultaneous slots (kernels_blob.hip, k_rowscan)
-    const int rs_shape = c->rowscan_shape >= 0 ? c->rowscan_shape : (k1_wg == 64 ? kRowscan1x2 : kRowscan4x4);
+    const int rs_shape = c->rowscan_shape >= 0 ? c->rowscan_shape : kRowscan4x4;      // (one-wave shapes beside the one-wave per-pixel kernel: slower, profiles/r07a_rowscan_shape_ab.txt)
     c->last_k1_wg = k1_wg;
     c->last_step_early = early;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be

@@ -55,10 +55,7 @@ constexpr int kLiveShift = 2;             // live bit of slot k is bit kLiveShif
 // and a lane that needs a later mode touches ONE half-sector of it instead of a sector in each of four planes.
 // (Round 1 and the first half of round 2 kept 25 scalar planes; profiles/r02_k1_layout_ab.txt also has the
 // measurements of 256-pixel tile records and of the nontemporal cache policy, both rejected.)
-#ifndef OATGPU_PAD
-#define OATGPU_PAD 0
-#endif
-constexpr size_t kPlanePad = OATGPU_PAD;     // floats between consecutive planes (A/B knob: DRAM channel alignment of the ten streams)
+constexpr size_t kPlanePad = 0;     // floats between consecutive planes (DRAM channel alignment of the ten streams was an A/B knob: no gain)
 __host__ __device__ inline size_t mog_stream_floats(int Palloc) { return (size_t)kMogPlanes * Palloc + 10 * kPlanePad; }
 __host__ __device__ inline size_t mog_w_off(int Palloc, int ch, int k) { return (size_t)k * ((2 + ch) * (size_t)Palloc + 2 * kPlanePad); }
 __host__ __device__ inline size_t mog_vm_off(int Palloc, int ch, int k) { return mog_w_off(Palloc, ch, k) + Palloc + kPlanePad; }
@@ -217,7 +214,7 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k);
 //       kBlobGlobal = row scan + k_merge + k_green_select.
 enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
 // workgroup shape of the row scan (kernels_blob.hip, k_rowscan): four waves with a row each, or ONE wave taking 4 / 2 / 1 rows
-enum { kRowscan4x4 = 0, kRowscan1x4 = 1, kRowscan1x2 = 2, kRowscan1x1 = 3 };
+enum { kRowscan4x4 = 0, kRowscan1x4 = 1, kRowscan1x2 = 2, kRowscan1x1 = 3, kRowscan8x8 = 4, kRowscan16x16 = 5, kRowscan2x2 = 6 };
 constexpr int kNeedsGlobal = -2;
 constexpr int kPathTimeout = 2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,

@@ -214,8 +214,12 @@ static void mog2_rows(oat_mog2 *m, const uint8_t *image, uint8_t *maskimg,
                         for (int c = 0; c < nchannels; c++)
                             mean_m[c] -= k * dData[c];
                         float varnew = var + k * (dist2 - var);
-                        varnew = varnew > varMin ? varnew : varMin;   /* MAX(varnew,varMin) */
-                        varnew = varnew < varMax ? varnew : varMax;   /* MIN(varnew,varMax) */
+                        /* OpenCV's macros, operand order kept: MAX(a,b) ((a) < (b) ? (b) : (a)), MIN(a,b) ((a) > (b) ? (b) : (a)).
+                           A NaN varnew (k = 0/0: a pruned slot re-matched at learning rate 0) compares false and STAYS NaN.
+                           [OCV-mem] recalled, not read; rounds 1-4 had the comparisons the other way round, which clamps a NaN
+                           to varMin.  Unreachable from stock Oat (one fixed rate a process). */
+                        varnew = varnew < varMin ? varMin : varnew;   /* MAX(varnew,varMin) */
+                        varnew = varnew > varMax ? varMax : varnew;   /* MIN(varnew,varMax) */
                         gmm[mode].variance = varnew;
                         /* sort: only the matched mode may have to move up */
                         for (int i = mode; i > 0; i--) {

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O; cd $R
 cat $O/r07a_smoke.txt
 {
 for s in 0 1 2 3 0 2; do
-  OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/oat_amd/lib/liboatgpu_meas.so OATGPU_ROWSCAN_SHAPE=$s timeout -k 5 300 python bench.py --workload 4k1 --steps 1000 --quick --check-steps 16 --detail-out $O/r07a_rs$s.json > $O/r07a_rs$s.line 2> $O/r07a_rs$s.log < /dev/null
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/build/variants/liboatgpu_meas.so OATGPU_ROWSCAN_SHAPE=$s timeout -k 5 300 python bench.py --workload 4k1 --steps 1000 --quick --check-steps 16 --detail-out $O/r07a_rs$s.json > $O/r07a_rs$s.line 2> $O/r07a_rs$s.log < /dev/null
   python - $O/r07a_rs$s.json $s <<'PY'
 import json, sys
 try:

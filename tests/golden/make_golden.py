@@ -64,7 +64,7 @@ def mog2_pixel_trace(pixels, rates, nmix=5, restore=True):
                     for c in range(3):
                         mu[mode][c] = f32(mu[mode][c] - f32(k * d[c]))
                     vn = f32(v + f32(k * f32(dist2 - v)))
-                    vn = max(vn, varMin); vn = min(vn, varMax)
+                    vn = varMin if vn < varMin else vn; vn = varMax if vn > varMax else vn     # OpenCV MAX / MIN macros: a NaN stays NaN
                     var[mode] = f32(vn)
                     i = mode
                     while i > 0:

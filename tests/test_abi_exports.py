@@ -96,3 +96,9 @@ def test_oatgpu_lib_redirect_needs_the_measure_switch(monkeypatch):
     assert ffi.lib_path() == product
     monkeypatch.setenv("OATGPU_MEASURE_PY", "1")
     assert ffi.lib_path() == "/tmp/some_other_build.so"
+
+
+def test_only_the_product_library_sits_beside_the_binding():
+    """A/B builds live under build/variants (make variant): nothing but liboatgpu.so in oat_amd/lib."""
+    libdir = os.path.join(ROOT, "oat_amd", "lib")
+    assert sorted(f for f in os.listdir(libdir) if f.endswith(".so")) == ["liboatgpu.so"]

@@ -37,8 +37,8 @@ def _same_detection(got, want, tag=""):
 
 def _eq(a, b):
     """Equal, a NaN being equal to a NaN: with the reference's `nmodes = nNewModes;` a pruned slot (weight 0) that
-    is matched again at learning rate 0 gets k = alphaT / weight = 0 / 0 -- its mean is NaN from then on, on both
-    sides (the variance clamps to varMin: `NaN > varMin` is false)."""
+    is matched again at learning rate 0 gets k = alphaT / weight = 0 / 0 -- its mean AND its variance are NaN from then
+    on, on both sides (OpenCV's MAX / MIN macros keep a NaN on the left: `NaN < varMin` is false)."""
     return ((a == b) | (np.isnan(a) & np.isnan(b))).all()
 
 
@@ -173,6 +173,42 @@ def test_mog2_mask_and_model_parity(A, shape, rate, restore):
         assert (mg == mo).all(), (shape, rate, t, int((mg != mo).sum()))
         if t % 20 == 19 or t < 3:
             _same_state(g.mog_state(), o.state(), (shape, rate, t))
+
+
+def test_mog2_nan_variance_of_a_rematched_pruned_slot(A):
+    """k = alphaT / weight = 0 / 0: a pruned slot (weight 0, kept by `nmodes = nNewModes;`) matched again at learning rate 0.
+    OpenCV's MAX / MIN macros keep the NaN variance (a comparison with a NaN is false) -- v_maximum3_f32 / v_minimum3_f32 in
+    the kernel, the macro's comparisons in the oracle (rounds 1-4 clamped it to varMin on both sides).
+    Stage-by-stage call and the fused pipelined path (one and two frames a launch), masks and the whole model."""
+    rows, cols = 8, 64
+    a = np.full((rows, cols, 3), 40, np.uint8)
+    b = np.full((rows, cols, 3), 200, np.uint8)
+    seq = [(a, 0.3)] * 3 + [(b, 0.3)] + [(a, 0.3)] * 40 + [(b, 0.0)] * 3 + [(a, 0.0), (b, 0.0), (a, 0.01), (b, 0.01)] * 3
+    g = A.BackgroundSubtractorMOG(rows, cols)
+    o = O.Mog2(rows, cols, 3)
+    for t, (f, rate) in enumerate(seq):
+        assert (g.apply(f, learning_rate=rate) == o.apply(f, rate)).all(), t
+        if t == 46:
+            nm, w, v, m = o.state()
+            assert nm[0] == 2 and w[0, 1] == 0.0 and np.isnan(v[0, 1]) and np.isnan(m[0, 1]).all()      # the case IS reached
+            gv = g.mog_state()[2]
+            assert np.isnan(gv[:, 1]).all()
+        _same_state(g.mog_state(), o.state(), t)
+    for fusion in (1, 2):
+        hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, v_thresh=(100, 256), erode=0, dilate=0, area=(0.5, 1e9))
+        hp.set_fusion(fusion)
+        o = O.Mog2(rows, cols, 3)
+        for t, (f, rate) in enumerate(seq):
+            hp.learning_coeff_ = rate
+            hp.enqueue([f])
+            o.apply(f, rate)
+            if hp.outstanding() == 3:
+                hp.collect()
+        while hp.outstanding():
+            hp.collect()
+        _same_state(hp.mog_state(), o.state(), ("fused", fusion))
+        assert np.isnan(hp.mog_state()[2][:, 1]).all()
+        hp.close()
 
 
 def test_mog2_single_pixel_traces(A, golden_dir):

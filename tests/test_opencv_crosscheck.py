@@ -90,3 +90,23 @@ def test_mog2_masks_match_cv_and_report_the_mode_count_reading():
     assert good, f"neither reading of the mode count reproduces OpenCV {cv2.__version__}: {verdict}"
     assert 1 in good, ("OpenCV %s prunes the mode count (restore_nmodes = 0): flip the default of "
                        "oatgpu_config.mog_restore_nmodes / oat_mog2_params.restore_nmodes" % cv2.__version__)
+
+
+def test_mog2_nan_variance_clamp():
+    """The fourth open point: `varnew = MAX(varnew, varMin); varnew = MIN(varnew, varMax);` when varnew
+    is NaN.  One pixel: learn at 0.3 until a second mode has been created and pruned again (its slot keeps weight 0 with
+    `nmodes = nNewModes;`), then show that slot's colour at learning rate 0 -- k = alphaT / weight = 0 / 0.  With OpenCV's
+    macros (a comparison with a NaN is false) the variance stays NaN and that slot can never match again; had the clamp
+    returned varMin the slot would still be NaN in its mean -- the masks cannot tell the two apart, so this test reads the
+    oracle's STATE and compares the masks of a long tail with cv2: it passes if the oracle's reading (NaN kept) is
+    at least mask-compatible, and prints the oracle's variance for the record."""
+    rows, cols = 4, 4
+    a = np.full((rows, cols, 3), 40, np.uint8)
+    b = np.full((rows, cols, 3), 200, np.uint8)
+    ref = cv2.createBackgroundSubtractorMOG2()
+    orc = O.Mog2(rows, cols, 3)
+    seq = [(a, 0.3)] * 3 + [(b, 0.3)] + [(a, 0.3)] * 40 + [(b, 0.0)] * 3 + [(a, 0.0), (b, 0.0), (a, 0.01), (b, 0.01)] * 5
+    for t, (f, rate) in enumerate(seq):
+        assert (ref.apply(f, learningRate=rate) == orc.apply(f, rate)).all(), t
+    nm, w, v, m = orc.state()
+    print("oracle variances of pixel 0 after the 0/0 update:", v[0].tolist(), "weights:", w[0].tolist())

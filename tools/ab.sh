@@ -5,7 +5,7 @@ out=$1; variants=$2; IFS=';' read -ra sets <<< "$3"
 mkdir -p "$out"
 for v in $variants; do
   for i in "${!sets[@]}"; do
-    lib=oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
+    lib=build/variants/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
     OATGPU_MEASURE_PY=1 OATGPU_LIB=$PWD/$lib python bench.py ${sets[$i]} --quick --check-steps 16 $AB_EXTRA --detail-out "$out/${v}_$i.json" > "$out/${v}_$i.line" 2> "$out/${v}_$i.log"
     python - "$out/${v}_$i.json" "$v" "${sets[$i]}" <<'PY'
 import json, sys

@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "contour o
 timeout 600 python tools/fuzz.py --configs 300 > $out/fuzz.txt 2>&1; tail -2 $out/fuzz.txt
 bash tools/ab.sh $out "$variants" "--workload 4k1 --steps 1000;--workload 1080p16 --steps 200 --warmup 40;--workload 1080p1 --steps 1500" | tee $out/ab.txt
 for v in $variants; do
-  lib=$R/oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=$R/oat_amd/lib/liboatgpu.so
+  lib=$R/build/variants/liboatgpu_$v.so; [ "$v" = default ] && lib=$R/oat_amd/lib/liboatgpu.so
   echo "== ktrace 4k1 pipelined, variant '$v'" | tee -a $out/ab.txt
   OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib bash tools/ktrace.sh $out/kt_$v.md --workload 4k1 --steps 1000 --warmup 40 | grep -E "kernel \||k_blob_lds|k_mog_fused|k_rowscan" | tee -a $out/ab.txt
   echo "== ktrace 1080p1 pipelined, variant '$v'" | tee -a $out/ab.txt

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "| cut | up to | VALU / wave | SALU / wave | VMEM rd / wave | us |"
 echo "|---|---|---|---|---|---|"
 for n in 1 2 3 4 5 base; do
-  lib=$R/oat_amd/lib/liboatgpu_cut$n.so; [ $n = base ] && lib=$R/oat_amd/lib/liboatgpu_base.so
+  lib=$R/build/variants/liboatgpu_cut$n.so; [ $n = base ] && lib=$R/build/variants/liboatgpu_base.so
   rm -rf /tmp/cutp
   OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d /tmp/cutp -o r -- python $R/tools/cut_profile.py run "$@" /tmp/cut_state > /dev/null 2> /tmp/cutp.err || tail -2 /tmp/cutp.err
   db=$(find /tmp/cutp -name "*.db" | head -1)

@@ -1,5 +1,5 @@
 for v in ${VARIANTS:-default default}; do
-  lib=oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
+  lib=build/variants/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
   OATGPU_MEASURE_PY=1 OATGPU_LIB=$PWD/$lib python bench.py --workload 4k1 --steps 300 --quick --check-steps 16 --detail-out /tmp/det_check.json > /dev/null 2>&1; cat /tmp/det_check.json | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j['roofline']['benched_workload']

@@ -7,7 +7,7 @@ mkdir -p $out
 for r in $(seq $reps); do
   for c in $combos; do
     v=${c%%:*}; lds=""; [[ $c == *:* ]] && lds=${c##*:}
-    lib=oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
+    lib=build/variants/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
     for leg in $legs; do
       case $leg in
         d) args="--workload 4k1 --dense-model --fusion 1 --steps 300 --warmup 1200 --quick --no-parity";;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel phase times of k_blob_lds, beside the per-pixel kernel (pipelined run) and alone (synchronous steps):
 
-    OATGPU_LIB=oat_amd/lib/liboatgpu_ldst.so python tools/lds_phase_probe.py [--workload 4k1] [--mode load|alone]
+    OATGPU_LIB=build/variants/liboatgpu_ldst.so python tools/lds_phase_probe.py [--workload 4k1] [--mode load|alone]
 
 Needs a -DOATGPU_LDS_TIMING build (make variant NAME=ldst DEFS=-DOATGPU_LDS_TIMING): its k_blob_lds stamps the 100 MHz
 wall clock between its phases into a ring in device memory, which oatgpu_debug_lds_timing copies out.  Run under

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/lds_phase_probe.py under rocprofv3 --kernel-trace, both modes:   tools/lds_phase_probe.sh OUTDIR [workload]
 out=${1:-gpurun_out/ldsp}; wl=${2:-4k1}; R=$PWD; mkdir -p $R/$out
-export OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/oat_amd/lib/liboatgpu_ldst.so
+export OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/build/variants/liboatgpu_ldst.so
 cd /tmp && export TMPDIR=/tmp
 for mode in load alone; do
   rm -rf /tmp/lp_$mode

@@ -2,7 +2,7 @@
 # bench lines WITH the PMC child passes for several library variants on one box: tools/pmc_ab.sh OUTDIR "variants"
 out=$1; mkdir -p $out
 for v in $2; do
-  lib=oat_amd/lib/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
+  lib=build/variants/liboatgpu_$v.so; [ "$v" = default ] && lib=oat_amd/lib/liboatgpu.so
   OATGPU_MEASURE_PY=1 OATGPU_LIB=$PWD/$lib python bench.py --no-extra --no-cpu-baseline --check-steps 16 --detail-out $out/$v.json > $out/$v.line 2> $out/$v.log
   python - $out/$v.json $v <<'PY'
 import json, sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Stream A kept off n compute units (OATGPU_A_RESERVE, measurement build liboatgpu_meas.so):  tools/reserve_ab.sh OUT "0 4 8 16"
 out=${1:-gpurun_out/rsv}; ns=${2:-"0 4 8"}; R=$PWD; mkdir -p $out
-export OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/oat_amd/lib/liboatgpu_meas.so
+export OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/build/variants/liboatgpu_meas.so
 for n in $ns; do
   export OATGPU_A_RESERVE=$n
   for set in "--workload 4k1 --steps 1000" "--workload 1080p16 --steps 200 --warmup 40" "--workload 1080p1 --steps 1500"; do
