@@ -163,33 +163,26 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // as cvStartFindContours does in OpenCV 3.1), the run-start bits T, the start
 // x of the run entering every word, and initialises the union-find at run heads.
 //
-// Workgroup shape <WAVES, ROWS>: a workgroup owns ROWS consecutive rows, wave w takes rows w, w + WAVES, ...
-//   <4, 4>  four waves, a row each: the shortest kernel on an idle device (12 us at 4K);
-//   <1, R>  ONE wave a workgroup, R rows one after the other.  Beside a per-pixel launch made of one-wave workgroups
-//           (k_mog_fused, WG = 64) a four-wave workgroup waits for four free wave slots on ONE compute unit at the same
-//           instant while every slot that frees up is refilled at once by the other queue: 12 us alone became 65-76 us
-//           beside it (profiles/r05q_kernel_stats_4k1_sparse.md).  A one-wave workgroup takes any slot, like its rival.
-#ifdef OATGPU_RS_TIMING             // measurement builds only (make variant DEFS=-DOATGPU_RS_TIMING, tools/rowscan_probe.py)
-constexpr unsigned kRsTkRing = 1u << 16;
-__device__ long long g_rs_tk[kRsTkRing * 4u];       // {first instruction, last instruction, workgroup, tag} of a workgroup (100 MHz wall clock)
-__device__ unsigned g_rs_tk_n;
-extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(long long *out, int max_rows)
-{
-    unsigned n = 0;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rs_tk_n), sizeof n) != hipSuccess) return -1;
-    const unsigned rows = n < kRsTkRing ? n : kRsTkRing;
-    const unsigned take = rows < (unsigned)max_rows ? rows : (unsigned)max_rows;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_tk), (size_t)take * 4u * sizeof(long long)) != hipSuccess) return -1;
-    return (int)take;
-}
-#endif
-
-template <bool ERODE, int WAVES, int ROWS>
-__global__ __launch_bounds__(64 * WAVES) void k_rowscan(Geom g, const u64 *src_all, int ero_k, int dil_k, BlobBuffers b,
-                                                        int first_stream, int clear_lds_ok, unsigned tag)
+// Workgroup shape: four waves, a row each.  Other shapes were measured beside the one-wave per-pixel launch of the early
+// order (r07, profiles/r07a_rowscan_shape_ab.txt, r07e_rowscan_shape_ab.txt, r07h_timeline.txt): ONE wave a workgroup taking
+// 4 / 2 / 1 rows in turn -- no earlier start, a longer chain per wave: gpu_total 243-263 -> 368-432 us; 8 / 16 waves a
+// workgroup -- the whole launch runs in 16-21 us once it is in, but waits 60 us and more for room on one compute unit
+// (it gets in when the per-pixel launch drains): no gain either.  The in-kernel clocks (tools/rowscan_probe.py, -DOATGPU_RS_TIMING)
+// say where the 55-60 us of this kernel beside the per-pixel kernel go: a workgroup RUNS 7 us (9 p90), the 540 workgroups of a 4K
+// frame START over 35 us -- the dispatcher hands this queue ~15 workgroups a microsecond while the per-pixel launch streams
+// 1 300 a microsecond through the other.
+constexpr int kRsWaves = 4, kRsRows = 4;
+// blockIdx.z selects one of TWO frames (source mask, scratch set): the two frames of a two-frame step are scanned by ONE
+// launch (launch_blob_pair: a launch is ~4 us of host time, and small frames are bound by exactly that).
+template <bool ERODE>
+__global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *src0, const u64 *src1, int ero_k, int dil_k, BlobBuffers b0,
+                                                        BlobBuffers b1, int first_stream, int clear_lds_ok, unsigned tag)
 {
     extern __shared__ u64 er[];
+    constexpr int WAVES = kRsWaves, ROWS = kRsRows;
+    const bool second = blockIdx.z != 0;
+    const BlobBuffers &b = second ? b1 : b0;
+    const u64 *src_all = second ? src1 : src0;
 #ifdef OATGPU_RS_TIMING
     const long long rs_t0 = wall_clock64();
 #endif
@@ -337,35 +330,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_rowscan(Geom g, const u64 *src_a
 #endif
 }
 
-template <bool ERODE, int WAVES, int ROWS>
-static void launch_rowscan_as(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
-                              int n_streams, int clear, hipStream_t st, unsigned tag)
+size_t rowscan_lds_bytes(const Geom &g, int dil_k)
 {
-    const size_t lds = ERODE ? (size_t)(ROWS + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64) : 0;
-    hipLaunchKernelGGL((k_rowscan<ERODE, WAVES, ROWS>), dim3((g.H + ROWS - 1) / ROWS, n_streams), dim3(64 * WAVES), lds, st, g,
-                       src_bits, ERODE ? ero_k : 0, dil_k, b, first_stream, clear, tag);
+    return (size_t)(kRsRows + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64);
 }
-// shape: kRowscan4x4 (four waves a workgroup, a row each), kRowscan1xN (one wave a workgroup, N rows in turn)
-static void launch_rowscan(const Geom &g, const u64 *src_bits, int ero_k, int dil_k, const BlobBuffers &b, int first_stream,
-                           int n_streams, int clear, hipStream_t st, int shape, unsigned tag = 0u)
+
+// src / b: nf (1 or 2) frames' source masks and scratch sets
+static void launch_rowscan(const Geom &g, const u64 *const *src, int ero_k, int dil_k, const BlobBuffers *b, int nf, int first_stream,
+                           int n_streams, int clear, hipStream_t st, unsigned tag = 0u)
 {
-    const bool e = ero_k > 1;
-    switch (shape) {
-    case kRowscan1x4: e ? launch_rowscan_as<true, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 1, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    case kRowscan1x2: e ? launch_rowscan_as<true, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 1, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    case kRowscan1x1: e ? launch_rowscan_as<true, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 1, 1>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    case kRowscan8x8: e ? launch_rowscan_as<true, 8, 8>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 8, 8>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    case kRowscan16x16: e ? launch_rowscan_as<true, 16, 16>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                          : launch_rowscan_as<false, 16, 16>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    case kRowscan2x2: e ? launch_rowscan_as<true, 2, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 2, 2>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    default:          e ? launch_rowscan_as<true, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag)
-                        : launch_rowscan_as<false, 4, 4>(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, tag); break;
-    }
+    const int k = nf > 1 ? 1 : 0;
+    const dim3 grid((g.H + kRsRows - 1) / kRsRows, n_streams, nf), block(64 * kRsWaves);
+    if (ero_k > 1)
+        hipLaunchKernelGGL(k_rowscan<true>, grid, block, rowscan_lds_bytes(g, dil_k), st, g, src[0], src[k], ero_k, dil_k, b[0], b[k],
+                           first_stream, clear, tag);
+    else
+        hipLaunchKernelGGL(k_rowscan<false>, grid, block, 0, st, g, src[0], src[k], 0, dil_k, b[0], b[k], first_stream, clear, tag);
 }
 
 // ------------------------------------------------------------ union-find -----
@@ -1202,18 +1182,14 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
     }
 }
 
-size_t rowscan_lds_bytes(const Geom &g, int dil_k)
-{
-    return (size_t)(4 + (dil_k > 1 ? dil_k : 1) - 1) * g.words * sizeof(u64);
-}
 
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode, int rowscan_shape)
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode)
 {
     const bool lds_able = g.H > 2 && g.H <= 16383 && g.W <= 16383;
     if (mode == kBlobSpec && !lds_able) mode = kBlobFull;
     const int clear = mode == kBlobGlobal || !lds_able;          // nobody else resets lds_ok then
-    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, clear, st, rowscan_shape);
+    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, clear, st);
     if (lds_able && mode != kBlobGlobal)
         hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams), dim3(kLdsBlock), 0, st, g, b, b, min_area, max_area, results, results,
                            first_stream, mode == kBlobSpec ? 1 : 0, 0u, 0u);
@@ -1236,12 +1212,22 @@ __global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned tic
     __hip_atomic_store(&ready[first_stream + threadIdx.x], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st, int rowscan_shape)
+                           int n_streams, unsigned ticket, hipStream_t st)
 {
-    launch_rowscan(g, src_bits, ero_k, dil_k, b, first_stream, n_streams, 0, st, rowscan_shape, ticket);
+    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, 0, st, ticket);
     for (int s0 = 0; s0 < n_streams; s0 += 1024)
         hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
                            first_stream + s0, ticket);
+}
+
+// The back halves of the TWO frames of a step as two launches instead of four (speculative mode: row scan + the LDS
+// kernel; a declined frame comes back marked kNeedsGlobal): frame i reads src[i] and scratch set b[i], writes results[i].
+void launch_blob_pair(const Geom &g, const BlobBuffers *b, const u64 *const *src, int ero_k, int dil_k, double min_area,
+                      double max_area, ResultRec *const *results, int n_streams, hipStream_t st)
+{
+    launch_rowscan(g, src, ero_k, dil_k, b, 2, 0, n_streams, 0, st);
+    hipLaunchKernelGGL(k_blob_lds, dim3(1, n_streams, 2), dim3(kLdsBlock), 0, st, g, b[0], b[1], min_area, max_area, results[0],
+                       results[1], 0, 1, 0u, 0u);
 }
 
 // The early blob workgroups of the nf (1 or 2) frames of a step in ONE launch: frame i reads scratch set b[i], writes

@@ -51,6 +51,7 @@ struct oatgpu_ctx {
     bool private_streams = false;   // OATGPU_PRIVATE_STREAMS: streams of its own instead of the device's shared ones
     bool have_shared = false;
     static constexpr int kNB = 4;
+    static constexpr int kSets = 5;              // scratch sets of the back half: up to four for frames in flight + one for repairs
     int nb = 3;                                  // back-half streams / scratch sets in use (OATGPU_NB: 1..4)
     bool b_used[kNB] = {};          // B streams this context has launched on (the only ones it ever has to drain)
     hipStream_t stream_b[kNB] = {}; // streams B0..B2: morphology + blob analysis, frame t on B[t % nb],
@@ -90,8 +91,8 @@ struct oatgpu_ctx {
     int expt = 0;
     // Early dispatch of the blob workgroup (kernels_blob.hip): the row scans of a device-frame step go down B0 / B1 by frame
     // parity, as on the plain path; the k_blob_lds workgroups of the step's frames are submitted with them as ONE launch on
-    // B2 and wait on the device for their row scans' tickets.  Scratch sets 0 / 1 by frame parity; repairs of declined
-    // frames use set 2 on B2.
+    // B2 and wait on the device for their row scans' tickets.  Scratch sets 0 .. 3 by frame index mod 4; repairs of declined
+    // frames use set 4 on B2.
     int early_blob = -1;             // -1: by shape -- at most THREE streams, 4 MP a step and more, where the per-pixel kernel then runs with one wave
                                      // a workgroup (k_mog_fused, WG): 4K 18.5 k -> 19.2 k fps, result 245 -> 250 us behind its frame
                                      // (profiles/r05g_wg64_early_blob_ab.txt).  With 256-thread workgroups the parked workgroup costs
@@ -107,14 +108,18 @@ struct oatgpu_ctx {
     unsigned long long early_timeouts = 0;   // frames whose parked blob workgroup gave up waiting for its row scan (kWaitTicks):
                                      // something serialises kernel dispatches -- the context then stops parking (early_off)
     bool early_off = false;
-    int rowscan_shape = -1;          // -1: by path (one-wave workgroups beside a one-wave per-pixel launch); measurement builds: OATGPU_ROWSCAN_SHAPE=0..3
     int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
     bool last_step_early = false;
-    int last_early = -1;             // path of the previous step (-1: none yet): a switch drains the B streams first
-    unsigned bh_ticket[kNB] = {};
+    int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
+    int early_sets = 4;              // scratch sets the early order cycles through (measurement builds: OATGPU_EARLY_SETS=2, the r04-r06 layout)
+    int nsets = 0;                   // scratch sets allocated (nb with the context; 4 once the paired back half has run)
+    int pair_back = 1;               // two-frame steps outside the early order: ONE row-scan launch and ONE blob launch for both frames
+                                     // (measurement builds: OATGPU_PAIR_BACK=0)
+    unsigned pair_steps = 0;         // paired steps so far (their parity picks the B stream and the two scratch sets)
+    unsigned bh_ticket[kSets] = {};
     unsigned early_frames = 0;       // frames that took the early path (their parity picks scratch set and row-scan stream)
-    hipEvent_t ev_blob[kNB] = {};    // scratch set q: its latest reader is done
-    bool ev_blob_valid[kNB] = {};
+    hipEvent_t ev_blob[kSets] = {};  // scratch set q: its latest reader is done
+    bool ev_blob_valid[kSets] = {};
     std::vector<char> slot_st;       // per ring slot: B stream its result event was recorded on / its repair goes to
     bool use_graph = false;                           // back half replayed from a captured hipGraph per slot
     std::vector<char> slot_filtered;                  // [ring_slots] was the position filter applied to this slot?
@@ -162,7 +167,7 @@ struct oatgpu_ctx {
     uint8_t *diff_last = nullptr;  // [n][H*W] previous GREY frame of posidet diff, allocated on first use
     std::vector<char> diff_have;   // per camera stream
     u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
-    BlobBuffers bb[kNB]{};            // one scratch set per frame parity (bb[0].thr holds both thr buffers)
+    BlobBuffers bb[kSets]{};          // scratch sets (bb[0].thr holds the ring's threshold buffers): nb made with the context, the rest on first use
     const u64 *last_morph = nullptr;
     const u64 *last_fin = nullptr;
     ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
@@ -399,10 +404,8 @@ static void free_all(oatgpu_ctx *c)
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
-    for (int q = 0; q < oatgpu_ctx::kNB; ++q) {
-        if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
-        if (c->ev_blob[q]) hipEventDestroy(c->ev_blob[q]);
-    }
+    for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->ev_k1[q]) hipEventDestroy(c->ev_k1[q]);
+    for (int q = 0; q < oatgpu_ctx::kSets; ++q) if (c->ev_blob[q]) hipEventDestroy(c->ev_blob[q]);
     for (auto ge : c->back_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto e : c->ring_ev) hipEventDestroy(e);
     for (auto &p : c->prof_steps) for (auto e : p.e) hipEventDestroy(e);
@@ -444,6 +447,35 @@ static hipError_t open_device(int device, int *ndev)
     return e;
 }
 extern "C" int oatgpu_device_open_retries(void) { return g_open_retries.load(); }
+
+// One scratch set of the back half (BlobBuffers; about 30 bytes a pixel and stream), its counters zeroed.  Sets 0 .. nb-1 are
+// made with the context; the paired back half (launch_jobs) adds a fourth on first use.
+static bool alloc_scratch_set(oatgpu_ctx *c, int q)
+{
+    const Geom &g = c->g;
+    const size_t n = c->cfg.n_streams, PA = g.Palloc, NW = PA / 64;
+    BlobBuffers &b = c->bb[q];
+    bool ok = true;
+    auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+    b.thr = c->bb[0].thr;
+    A((void **)&b.tmp, n * NW * 8);
+    A((void **)&b.morph, n * NW * 8);
+    A((void **)&b.fin, n * NW * 8);
+    A((void **)&b.trans, n * NW * 8);
+    A((void **)&b.carry, n * (size_t)g.H * g.words * sizeof(int));
+    A((void **)&b.parent, n * PA * sizeof(int));
+    A((void **)&b.acc, n * PA * 3 * sizeof(long long));
+    A((void **)&b.done, n * sizeof(unsigned));
+    A((void **)&b.roots, n * (PA / 2) * sizeof(int));
+    A((void **)&b.nroots, n * sizeof(unsigned));
+    A((void **)&b.wpre, n * (size_t)g.H * g.words * sizeof(unsigned short));
+    A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
+    A((void **)&b.lds_ok, n * sizeof(unsigned));
+    A((void **)&b.ready, n * sizeof(unsigned));
+    for (unsigned *p : {b.done, b.nroots, b.lds_ok, b.ready})
+        if (ok && hipMemsetAsync(p, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+    return ok;
+}
 
 extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
 {
@@ -521,11 +553,13 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     c->ring_slots = cfg->ring_depth;                  // slot = threshold buffer, slot % nb = scratch set / stream
     for (int q = 0; q < c->nb && ok; ++q) {
         ok = hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming | ((c->expt & 2) ? 0 : hipEventDisableSystemFence)) == hipSuccess;
-        if (ok) ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
+    for (int q = 0; q < oatgpu_ctx::kSets && ok; ++q)
+        ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
-    if (const char *e = measure_env("OATGPU_ROWSCAN_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 6) c->rowscan_shape = v; }
+    if (const char *e = measure_env("OATGPU_EARLY_SETS")) c->early_sets = atoi(e) == 2 ? 2 : 4;
+    if (const char *e = measure_env("OATGPU_PAIR_BACK")) c->pair_back = atoi(e) != 0;
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
 
@@ -539,24 +573,8 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // One threshold-bit buffer per ring slot: a slot is only reused after its result was collected,
     // i.e. after the back half that read its buffer has finished -- stream A never waits for a B stream.
     A((void **)&c->bb[0].thr, (size_t)c->ring_slots * n * NW * 8);
-    for (int q = 0; q < c->nb; ++q) {
-        BlobBuffers &b = c->bb[q];
-        b.thr = c->bb[0].thr;
-        A((void **)&b.tmp, n * NW * 8);
-        A((void **)&b.morph, n * NW * 8);
-        A((void **)&b.fin, n * NW * 8);
-        A((void **)&b.trans, n * NW * 8);
-        A((void **)&b.carry, n * (size_t)g.H * g.words * sizeof(int));
-        A((void **)&b.parent, n * PA * sizeof(int));
-        A((void **)&b.acc, n * PA * 3 * sizeof(long long));
-        A((void **)&b.done, n * sizeof(unsigned));
-        A((void **)&b.roots, n * (PA / 2) * sizeof(int));
-        A((void **)&b.nroots, n * sizeof(unsigned));
-        A((void **)&b.wpre, n * (size_t)g.H * g.words * sizeof(unsigned short));
-        A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
-        A((void **)&b.lds_ok, n * sizeof(unsigned));
-        A((void **)&b.ready, n * sizeof(unsigned));
-    }
+    for (int q = 0; q < c->nb && ok; ++q) ok = alloc_scratch_set(c, q);
+    c->nsets = c->nb;
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
@@ -583,13 +601,6 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     if (ok && hipMemsetAsync(c->nmodes, 0, n * PA, c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->state, 0, n * mog_stream_floats(g.Palloc) * sizeof(float), c->stream) != hipSuccess) ok = false;
     if (ok && hipMemsetAsync(c->bb[0].thr, 0, (size_t)c->ring_slots * n * NW * 8, c->stream) != hipSuccess) ok = false;
-    for (int q = 0; q < c->nb; ++q) {
-        BlobBuffers &b = c->bb[q];
-        if (ok && hipMemsetAsync(b.done, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
-        if (ok && hipMemsetAsync(b.nroots, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
-        if (ok && hipMemsetAsync(b.lds_ok, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
-        if (ok && hipMemsetAsync(b.ready, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
-    }
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     if (!ok) {
         fail(nullptr, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1131,7 +1142,7 @@ static void apply_kalman(const ResultRec &r, oatgpu_position *o)
 // erode -> (dilate fused into the row scan) -> blob for camera streams [s0, s0+n), reading
 // the threshold bits `thr`; results land in host-mapped slot `slot`.  All on HIP stream st.
 static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int n, int slot, hipStream_t st,
-                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1, int mode = kBlobFull, int rowscan_shape = kRowscan4x4)
+                     hipEvent_t ev_mid, int erode_k = -1, int dilate_k = -1, int mode = kBlobFull)
 {
     const Geom &g = c->g;
     const u64 *src = thr;
@@ -1148,7 +1159,7 @@ static int back_half(oatgpu_ctx *c, BlobBuffers &bb, const u64 *thr, int s0, int
     c->last_morph = (dil || ero) ? bb.morph : src;
     c->last_fin = bb.fin;
     ResultRec *rd = c->res_dev + (size_t)slot * c->cfg.n_streams;
-    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st, mode, rowscan_shape);
+    launch_blob(g, bb, src, ero, dil, c->cfg.min_area, c->cfg.max_area, rd, s0, n, st, mode);
     HIPCHK(c, hipGetLastError());
     return OATGPU_OK;
 }
@@ -1478,9 +1489,6 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // (streaming-load launches: K1 is 5-10 x the back half, 4K 6 670 -> 7 110 fps, profiles/r05n_dense_wg64_ab.txt; a result
     // is then ready ~230 us later, one K1 launch, because the blob workgroup gets in when the launch drains).
     const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads) ? 64 : 256;
-    // ... and the row scan's workgroups follow: beside a per-pixel launch of one-wave workgroups a four-wave workgroup starves
-    // for four simultaneous slots (kernels_blob.hip, k_rowscan)
-    const int rs_shape = c->rowscan_shape >= 0 ? c->rowscan_shape : kRowscan4x4;      // (one-wave shapes beside the one-wave per-pixel kernel: slower, profiles/r07a_rowscan_shape_ab.txt)
     c->last_k1_wg = k1_wg;
     c->last_step_early = early;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
@@ -1531,9 +1539,51 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
 
     if (k1_done && !k1_done_recorded) HIPCHK(c, hipEventRecord(k1_done, A));
 
-    if (c->last_early >= 0 && c->last_early != (int)early)          // the two paths use the scratch sets from different streams
+    // The paired back half: both frames of a two-frame step go through ONE row-scan launch and ONE k_blob_lds launch (grid z =
+    // frame) on ONE B stream behind one wait, one ring event covers both results -- 6 runtime calls a step instead of 10.
+    // Small frames are bound by exactly those calls (one 1080p stream: 30 us of per-pixel kernel a step under ~40 us of
+    // HIP calls).  Steps alternate between B0 / B1 with two scratch sets each, so consecutive steps' back halves overlap.
+    // Speculative mode only (row scan + LDS kernel; a declined frame is repaired from its threshold bits as on the other paths).
+    const int ero_cfg = c->cfg.erode > 1 ? c->cfg.erode : 0, dil_cfg = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+    const bool paired = nj == 2 && !early && c->pair_back && c->lds_spec && !c->kal_on && !c->serial && !c->use_graph && !(c->expt & 1) &&
+                        c->nb >= 2 && c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 &&
+                        !(ero_cfg && rowscan_lds_bytes(c->g, dil_cfg) > kRowscanLdsMax);
+    const int path = early ? 1 : paired ? 2 : 0;
+    if (c->last_early >= 0 && c->last_early != path)          // the paths use the scratch sets from different streams
         for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
-    c->last_early = (int)early;
+    c->last_early = path;
+    for (int q = c->nsets; q < (early ? 5 : paired ? 4 : 0); ++q) {           // first use: the scratch sets beyond the context's nb
+        if (!alloc_scratch_set(c, q)) return fail(c, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->nsets = q + 1;
+    }
+    if (paired) {
+        const Geom &g = c->g;
+        const int p = (int)(c->pair_steps++ & 1u);
+        hipStream_t B = c->stream_b[p];
+        c->b_used[p] = true;
+        HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
+        if (ps) { HIPCHK(c, hipEventRecord(ps->e[2], B)); HIPCHK(c, hipEventRecord(ps->e[3], B)); }
+        const BlobBuffers bbs[2] = {c->bb[2 * p], c->bb[2 * p + 1]};
+        const u64 *srcs[2] = {thr_buf(c, j[0].slot), thr_buf(c, j[1].slot)};
+        ResultRec *res[2] = {c->res_dev + (size_t)j[0].slot * n, c->res_dev + (size_t)j[1].slot * n};
+        launch_blob_pair(g, bbs, srcs, ero_cfg, dil_cfg, c->cfg.min_area, c->cfg.max_area, res, n, B);
+        HIPCHK(c, hipGetLastError());
+        if (ps) HIPCHK(c, hipEventRecord(ps->e[4], B));
+        for (int i = 0; i < 2; ++i) {
+            const int slot = j[i].slot;
+            c->slot_spec[slot] = 1;
+            c->slot_q[slot] = (char)(2 * p + i);          // a repair redoes the frame in its own scratch set ...
+            c->slot_st[slot] = (char)p;                   // ... on its step's B stream, behind whatever that is busy with
+            c->slot_filtered[slot] = 0;
+            c->slot_ev[slot] = j[1].slot;                 // one ring event behind the step's blob launch covers both results
+        }
+        c->last_morph = (dil_cfg || ero_cfg) ? bbs[1].morph : srcs[1];
+        c->last_fin = bbs[1].fin;
+        c->last_q = j[1].slot;
+        HIPCHK(c, hipEventRecord(c->ring_ev[j[1].slot], B));
+        return OATGPU_OK;
+    }
     if (early) {
         const Geom &g = c->g;
         hipStream_t C = c->stream_b[2];
@@ -1543,11 +1593,16 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
         unsigned tk[2] = {0, 0};
         int qs[2] = {0, 0};
         for (int i = 0; i < nj; ++i) {
-            // scratch set / row-scan stream by FRAME parity (not by ring slot: with an odd ring depth two consecutive frames
-            // can sit in slots of the same parity, and the two frames of a step must not share a scratch set)
-            const int slot = j[i].slot, q = (int)(c->early_frames++ & 1u);
+            // scratch set by FRAME index mod 4, row-scan stream by its parity (not by ring slot: with an odd ring depth two
+            // consecutive frames can sit in slots of the same parity, and the two frames of a step must not share a set).
+            // FOUR sets (r07; two until then): with two, a frame's row scan had to wait for the blob workgroup of the frame two
+            // before it -- the back half was a serial chain of row scan (~60 us beside the per-pixel kernel) + blob analysis
+            // (~30 us) per step, as long as the per-pixel kernel's own period: the row scan started 37 us behind its per-pixel
+            // launch, a result was ready ~125 us behind it (profiles/r07f_timeline_rowscan_shapes.txt).  With four, a step's row
+            // scans depend on nothing but their own per-pixel launch.
+            const int slot = j[i].slot, q = (int)(c->early_frames++ & (unsigned)(c->early_sets - 1));
             qs[i] = q;
-            hipStream_t R = c->stream_b[q];
+            hipStream_t R = c->stream_b[q & 1];
             ProfStep *pb = i == 0 ? ps : nullptr;
             BlobBuffers &bb = c->bb[q];
             // ---- B0 / B1: the frame's row scan, behind the step's per-pixel kernel and the last reader of scratch set q ----
@@ -1567,10 +1622,10 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->last_fin = bb.fin;
             unsigned ticket = ++c->bh_ticket[q];
             if (!ticket) ticket = ++c->bh_ticket[q];
-            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R, rs_shape);
+            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
             bbs[i] = bb; res[i] = c->res_dev + (size_t)slot * n; tk[i] = ticket;
             c->slot_spec[slot] = 1;
-            c->slot_q[slot] = 2;                         // a repair redoes the frame in scratch set 2 ...
+            c->slot_q[slot] = 4;                         // a repair redoes the frame in scratch set 4 ...
             c->slot_st[slot] = 2;                        // ... on B2, behind the blob launches
             c->slot_filtered[slot] = 0;
         }
@@ -1621,7 +1676,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->slot_spec[slot] = mode == kBlobSpec;
             c->slot_q[slot] = (char)q;
             c->slot_st[slot] = (char)q;
-            int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode, rs_shape);
+            int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode);
             if (rc) return rc;
         }
         if (c->kal_on) {

@@ -213,18 +213,18 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k);
 //                     the caller runs kBlobGlobal on the same threshold bits before it hands the result out;
 //       kBlobGlobal = row scan + k_merge + k_green_select.
 enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
-// workgroup shape of the row scan (kernels_blob.hip, k_rowscan): four waves with a row each, or ONE wave taking 4 / 2 / 1 rows
-enum { kRowscan4x4 = 0, kRowscan1x4 = 1, kRowscan1x2 = 2, kRowscan1x1 = 3, kRowscan8x8 = 4, kRowscan16x16 = 5, kRowscan2x2 = 6 };
 constexpr int kNeedsGlobal = -2;
 constexpr int kPathTimeout = 2;
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
-                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull,
-                 int rowscan_shape = kRowscan4x4);
+                 double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
 // The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan with a one-lane kernel behind
 // it that publishes `ticket`, and everything behind the row scan, whose k_blob_lds workgroup may be dispatched long before
 // the row scan has run and waits for `ticket` on the device.  ticket != 0.
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st, int rowscan_shape = kRowscan4x4);
+                           int n_streams, unsigned ticket, hipStream_t st);
+// both frames of a two-frame step: ONE row-scan launch and ONE k_blob_lds launch (speculative mode), lds-able geometries only
+void launch_blob_pair(const Geom &g, const BlobBuffers *b, const u64 *const *src, int ero_k, int dil_k, double min_area,
+                      double max_area, ResultRec *const *results, int n_streams, hipStream_t st);
 // the blob workgroups of the nf (1 or 2) frames of a step in ONE launch (speculative mode): arrays of nf scratch sets,
 // result records and tickets
 void launch_blob_tail2(const Geom &g, const BlobBuffers *b, double min_area, double max_area, ResultRec *const *results,

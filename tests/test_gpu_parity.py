@@ -207,7 +207,7 @@ def test_mog2_nan_variance_of_a_rematched_pruned_slot(A):
         while hp.outstanding():
             hp.collect()
         _same_state(hp.mog_state(), o.state(), ("fused", fusion))
-        assert np.isnan(hp.mog_state()[2][:, 1]).all()
+        assert np.isnan(hp.mog_state()[2]).any(1).all()          # (the NaN slot has moved down the list by now: later modes overtook it)
         hp.close()
 
 

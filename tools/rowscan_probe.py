@@ -47,8 +47,7 @@ def main():
     for r in range(n):
         t0, t1, wg, tag = buf[r * 4], buf[r * 4 + 1], buf[r * 4 + 2], buf[r * 4 + 3]
         launches[tag].append((t0, t1, wg))
-    rpw = {0: 4, 1: 4, 2: 2, 3: 1, 4: 8, 5: 16, 6: 2}[int(os.environ.get("OATGPU_ROWSCAN_SHAPE", "0"))]
-    nwg = (leg.wl["rows"] + rpw - 1) // rpw
+    nwg = (leg.wl["rows"] + 3) // 4
     # (early order: the two frames of a step carry the same ticket on their two scratch sets -- 2 x nwg entries a tag, run
     # side by side on two streams: split by first / second occurrence of a workgroup index in start order)
     full = []
