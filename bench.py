@@ -985,6 +985,38 @@ def scatter_leg(name, world, rank, dev, backend, steps, reduce_max, depth=2, gat
     return out
 
 
+def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_start):
+    """The scatter leg is the only part of an N > 1 run with a data-path exchange, and it runs LAST: should a transport hang
+    (a peer that died, a P2P path that does not come up), a timer ends the rank instead of the job's default 10-minute
+    collective timeout killing it without a line -- rank 0 first prints the line it already has, marked."""
+    import threading
+    done = threading.Event()
+
+    def fire():
+        if done.is_set():
+            return
+        log(f"[rank {rank}] scatter leg: no result within {args.scatter_timeout} s -- given up")
+        if rank == 0 and line_so_far is not None:
+            line_so_far["scatter_ingest"] = dict(error=f"no result within {args.scatter_timeout} s", parity="timeout",
+                                                 backend=args.backend)
+            line_so_far["bench_wall_s"] = time.perf_counter() - t_start
+            emit(line_so_far)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    t = threading.Timer(args.scatter_timeout, fire)
+    t.daemon = True
+    t.start()
+    try:
+        sc = scatter_leg(args.workload, world, rank, dev, args.backend, args.scatter_steps, reduce_max)
+    except Exception as e:
+        log(f"[rank {rank}] scatter leg failed:", e)
+        sc = dict(error=str(e)[-200:], parity="error", backend=args.backend)
+    done.set()
+    t.cancel()
+    return sc
+
+
 # ------------------------------------------------------------------ PMC legs --
 
 def pmc_child(args):
@@ -1276,6 +1308,7 @@ def main():
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: skip the scatter_ingest leg (frames from rank 0 through "
                                                               "the stream->rank scatter)")
     ap.add_argument("--scatter-steps", type=int, default=200, help="steps of the scatter_ingest leg (N > 1)")
+    ap.add_argument("--scatter-timeout", type=float, default=300.0, help="seconds after which a hanging scatter leg is given up")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
@@ -1385,16 +1418,7 @@ def main():
             one_lat = single_frame_latency(leg, 300)
         except Exception as e:
             log("single-frame latency probe failed:", e)
-    scatter = None
-    if world > 1 and not args.no_scatter and args.input == "device" and not args.dense_model:
-        try:
-            scatter = scatter_leg(args.workload, world, rank, dev, args.backend, args.scatter_steps, reduce_max)
-            if rank == 0:
-                log(f"scatter_ingest: {scatter['fps'] and round(scatter['fps'], 1)} fps, {scatter['ms_per_step']} ms/step, "
-                    f"{scatter['bytes_per_peer']} B/peer/step, parity {scatter['parity']}")
-        except Exception as e:
-            log(f"[rank {rank}] scatter leg failed:", e)
-            scatter = dict(error=str(e)[-200:], parity="error")
+    want_scatter = world > 1 and not args.no_scatter and args.input == "device" and not args.dense_model
 
     per_rank = None
     if world > 1:
@@ -1413,6 +1437,9 @@ def main():
 
     if rank != 0:
         if world > 1:
+            if want_scatter:
+                leg.close()
+                scatter_with_watchdog(args, world, rank, dev, reduce_max, None, t_start)
             dist.barrier()              # rank 0 prints before everybody leaves
             dist.destroy_process_group()
         return
@@ -1768,7 +1795,7 @@ def main():
         "rccl": ({"ranks": world, "backend": args.backend,
                   "version": ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
                  if world > 1 else None),
-        "scatter_ingest": scatter,
+        "scatter_ingest": None,
         "positions_found": n_found,
         "positions_expected": total_streams * tr["steps_timed"],
         "parity": parity,
@@ -1794,6 +1821,10 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.workload, pool_host0)
     else:
         line["cpu_baseline"] = None
+    if want_scatter:                               # last: nothing the line needs from the other ranks is still outstanding
+        line["scatter_ingest"] = scatter_with_watchdog(args, world, rank, dev, reduce_max, line, t_start)
+        sc = line["scatter_ingest"] or {}
+        log(f"scatter_ingest: {sc.get('fps')} fps, {sc.get('ms_per_step')} ms/step, {sc.get('bytes_per_peer')} B/peer/step, parity {sc.get('parity')}")
     line["bench_wall_s"] = time.perf_counter() - t_start
     emit(line)
     if world > 1:

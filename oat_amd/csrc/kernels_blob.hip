@@ -172,17 +172,61 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // frame START over 35 us -- the dispatcher hands this queue ~15 workgroups a microsecond while the per-pixel launch streams
 // 1 300 a microsecond through the other.
 constexpr int kRsWaves = 4, kRsRows = 4;
+
+#ifdef OATGPU_RS_TIMING             // measurement builds only (make variant DEFS=-DOATGPU_RS_TIMING, tools/rowscan_probe.py)
+constexpr unsigned kRsTkRing = 1u << 16;
+__device__ long long g_rs_tk[kRsTkRing * 4u];       // {first instruction, last instruction, row group, tag} of a row group (100 MHz wall clock)
+__device__ unsigned g_rs_tk_n;
+extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(long long *out, int max_rows)
+{
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rs_tk_n), sizeof n) != hipSuccess) return -1;
+    const unsigned rows = n < kRsTkRing ? n : kRsTkRing;
+    const unsigned take = rows < (unsigned)max_rows ? rows : (unsigned)max_rows;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_tk), (size_t)take * 4u * sizeof(long long)) != hipSuccess) return -1;
+    return (int)take;
+}
+#endif
 // blockIdx.z selects one of TWO frames (source mask, scratch set): the two frames of a two-frame step are scanned by ONE
 // launch (launch_blob_pair: a launch is ~4 us of host time, and small frames are bound by exactly that).
 template <bool ERODE>
 __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *src0, const u64 *src1, int ero_k, int dil_k, BlobBuffers b0,
-                                                        BlobBuffers b1, int first_stream, int clear_lds_ok, unsigned tag)
+                                                        BlobBuffers b1, int first_stream, int clear_lds_ok, unsigned tag,
+                                                        const unsigned *k1_flag, unsigned k1_ticket)
 {
     extern __shared__ u64 er[];
     constexpr int WAVES = kRsWaves, ROWS = kRsRows;
     const bool second = blockIdx.z != 0;
     const BlobBuffers &b = second ? b1 : b0;
     const u64 *src_all = second ? src1 : src0;
+    // The parked form (k1_flag): the launch is dispatched AHEAD of the per-pixel launch that writes its source mask, with a
+    // few persistent workgroups a stream (gridDim.x < row groups), which take their wave slots while the device still has
+    // them, wait -- one lane polls between s_sleeps, the others sit in the barrier -- until the stream memory operation behind
+    // that launch has raised *k1_flag to k1_ticket, and then walk the frame's row groups gridDim.x apart.
+    if (k1_flag) {
+        __shared__ int rs_wait_failed;
+        if (threadIdx.x == 0) {
+            int bad = 0;
+            const long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(k1_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k1_ticket) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 10000000ll) { bad = 1; break; }       // 100 ms of the 100 MHz wall clock
+            }
+            rs_wait_failed = bad;
+        }
+        __syncthreads();
+        if (rs_wait_failed) {
+            if (threadIdx.x == 0) atomicOr(&b.rs_bad[first_stream + blockIdx.y], 1u);
+            return;
+        }
+        // this workgroup was resident BEFORE its source mask was written: whatever its compute unit's L1 and its XCD's L2 hold of
+        // that ring slot's buffer is from eight frames ago
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int ngroups = (g.H + ROWS - 1) / ROWS;
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
 #ifdef OATGPU_RS_TIMING
     const long long rs_t0 = wall_clock64();
 #endif
@@ -193,7 +237,7 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
     const u64 *src_img = src_all + (size_t)s * (g.Palloc >> 6);
     const int dk = dil_k > 1 ? dil_k : 1;
     if (ERODE) {
-        const int r0 = blockIdx.x * ROWS - dk / 2;
+        const int r0 = grp * ROWS - dk / 2;
         const int n = (ROWS + dk - 1) * g.words;
         // Masks are mostly empty: if no bit is set in any row the erosion windows of this workgroup touch, the
         // eroded rows are zero (an image row never erodes to more than it holds) -- one pass over the source
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
 
 #pragma unroll 1
     for (int rr = wave; rr < ROWS; rr += WAVES) {
-    const int y = blockIdx.x * ROWS + rr;
+    const int y = grp * ROWS + rr;
     if (y >= g.H) break;
     const size_t woff = (size_t)s * (g.Palloc >> 6) + (size_t)y * g.words;
     u64 *morph = b.morph + woff;
@@ -323,11 +367,13 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
 #ifdef OATGPU_RS_TIMING
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         const unsigned slot = atomicAdd(&g_rs_tk_n, 1u) & (kRsTkRing - 1u);
-        g_rs_tk[slot * 4u] = rs_t0; g_rs_tk[slot * 4u + 1] = wall_clock64(); g_rs_tk[slot * 4u + 2] = blockIdx.x; g_rs_tk[slot * 4u + 3] = tag;
+        g_rs_tk[slot * 4u] = rs_t0; g_rs_tk[slot * 4u + 1] = wall_clock64(); g_rs_tk[slot * 4u + 2] = grp; g_rs_tk[slot * 4u + 3] = tag;
     }
 #else
     (void)tag;
 #endif
+    if (ERODE) __syncthreads();            // (persistent form: the next row group's erosion rewrites the LDS rows)
+    }
 }
 
 size_t rowscan_lds_bytes(const Geom &g, int dil_k)
@@ -337,15 +383,18 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k)
 
 // src / b: nf (1 or 2) frames' source masks and scratch sets
 static void launch_rowscan(const Geom &g, const u64 *const *src, int ero_k, int dil_k, const BlobBuffers *b, int nf, int first_stream,
-                           int n_streams, int clear, hipStream_t st, unsigned tag = 0u)
+                           int n_streams, int clear, hipStream_t st, unsigned tag = 0u, const unsigned *k1_flag = nullptr,
+                           unsigned k1_ticket = 0u, int park_groups = 0)
 {
     const int k = nf > 1 ? 1 : 0;
-    const dim3 grid((g.H + kRsRows - 1) / kRsRows, n_streams, nf), block(64 * kRsWaves);
+    const int groups = (g.H + kRsRows - 1) / kRsRows;
+    const dim3 grid(k1_flag && park_groups > 0 && park_groups < groups ? park_groups : groups, n_streams, nf), block(64 * kRsWaves);
     if (ero_k > 1)
         hipLaunchKernelGGL(k_rowscan<true>, grid, block, rowscan_lds_bytes(g, dil_k), st, g, src[0], src[k], ero_k, dil_k, b[0], b[k],
-                           first_stream, clear, tag);
+                           first_stream, clear, tag, k1_flag, k1_ticket);
     else
-        hipLaunchKernelGGL(k_rowscan<false>, grid, block, 0, st, g, src[0], src[k], 0, dil_k, b[0], b[k], first_stream, clear, tag);
+        hipLaunchKernelGGL(k_rowscan<false>, grid, block, 0, st, g, src[0], src[k], 0, dil_k, b[0], b[k], first_stream, clear, tag,
+                           k1_flag, k1_ticket);
 }
 
 // ------------------------------------------------------------ union-find -----
@@ -1207,16 +1256,20 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
 // end-of-kernel release make its output visible to agent-scope loads, one lane per stream publishes.  (The in-kernel
 // form -- k_rowscan storing what k_blob_lds reads write-through and its last-arriving workgroup publishing the ticket --
 // saved that launch and cost the per-pixel kernel 3-4 %: profiles/r04o_*, r04p_*.)
-__global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned ticket)
+// (rs_bad: a parked row scan that gave up waiting for its per-pixel launch publishes NOTHING -- the blob workgroup then times
+// out and declines the frame to the global kernels -- and is cleared for the scratch set's next frame)
+__global__ void k_publish_ticket(unsigned *ready, unsigned *rs_bad, int first_stream, unsigned ticket)
 {
-    __hip_atomic_store(&ready[first_stream + threadIdx.x], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int s = first_stream + threadIdx.x;
+    if (__hip_atomic_load(&rs_bad[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { rs_bad[s] = 0u; return; }
+    __hip_atomic_store(&ready[s], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st)
+                           int n_streams, unsigned ticket, hipStream_t st, const unsigned *k1_flag, unsigned k1_ticket, int park_groups)
 {
-    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, 0, st, ticket);
+    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, 0, st, ticket, k1_flag, k1_ticket, park_groups);
     for (int s0 = 0; s0 < n_streams; s0 += 1024)
-        hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
+        hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready, b.rs_bad,
                            first_stream + s0, ticket);
 }
 

@@ -111,6 +111,10 @@ struct oatgpu_ctx {
     int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
     bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
+    int rs_park = 0;                 // early order: persistent row-scan workgroups a stream, parked ahead of their per-pixel launch (0: off;
+                                     // measurement builds: OATGPU_RS_PARK=n)
+    unsigned *k1_flag = nullptr;     // device word the per-pixel stream raises behind every step's launch (hipStreamWriteValue32)
+    unsigned k1_ticket = 0;
     int early_sets = 4;              // scratch sets the early order cycles through (measurement builds: OATGPU_EARLY_SETS=2, the r04-r06 layout)
     int nsets = 0;                   // scratch sets allocated (nb with the context; 4 once the paired back half has run)
     int pair_back = 1;               // two-frame steps outside the early order: ONE row-scan launch and ONE blob launch for both frames
@@ -389,6 +393,7 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bb[0].thr);
     hipFree(c->kal.state);
     hipFree(c->audit_dev);
+    hipFree(c->k1_flag);
     hipFree(c->wild_sink);
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
@@ -400,7 +405,7 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
         hipFree(b.roots); hipFree(b.nroots); hipFree(b.wpre); hipFree(b.rowinfo); hipFree(b.lds_ok);
-        hipFree(b.ready);
+        hipFree(b.ready); hipFree(b.rs_bad);
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
@@ -472,7 +477,8 @@ static bool alloc_scratch_set(oatgpu_ctx *c, int q)
     A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
     A((void **)&b.lds_ok, n * sizeof(unsigned));
     A((void **)&b.ready, n * sizeof(unsigned));
-    for (unsigned *p : {b.done, b.nroots, b.lds_ok, b.ready})
+    A((void **)&b.rs_bad, n * sizeof(unsigned));
+    for (unsigned *p : {b.done, b.nroots, b.lds_ok, b.ready, b.rs_bad})
         if (ok && hipMemsetAsync(p, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     return ok;
 }
@@ -558,6 +564,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
+    if (const char *e = measure_env("OATGPU_RS_PARK")) c->rs_park = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = measure_env("OATGPU_EARLY_SETS")) c->early_sets = atoi(e) == 2 ? 2 : 4;
     if (const char *e = measure_env("OATGPU_PAIR_BACK")) c->pair_back = atoi(e) != 0;
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
@@ -701,6 +708,17 @@ extern "C" int oatgpu_set_early_blob(oatgpu_ctx *c, int32_t on)
     c->early_blob = on < 0 ? -1 : on != 0;
     return OATGPU_OK;
 }
+
+#ifdef OATGPU_MEASURE
+// measurement builds only (tools/dense_placement_probe.py): where the context's model, counters and frames landed
+extern "C" __attribute__((visibility("default"))) int oatgpu_debug_addresses(oatgpu_ctx *c, unsigned long long *out4)
+{
+    if (!c || !out4) return OATGPU_E_INVALID;
+    out4[0] = (unsigned long long)(uintptr_t)c->state; out4[1] = (unsigned long long)(uintptr_t)c->nmodes;
+    out4[2] = (unsigned long long)(uintptr_t)c->bb[0].thr; out4[3] = (unsigned long long)(mog_stream_floats(c->g.Palloc) * 4);
+    return OATGPU_OK;
+}
+#endif
 
 extern "C" int oatgpu_set_k1_workgroup(oatgpu_ctx *c, int32_t threads)
 {
@@ -1538,13 +1556,22 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     c->launched_total += (unsigned long long)nj;
 
     if (k1_done && !k1_done_recorded) HIPCHK(c, hipEventRecord(k1_done, A));
+    const int ero_cfg = c->cfg.erode > 1 ? c->cfg.erode : 0, dil_cfg = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
+    const bool park = early && c->rs_park > 0 && !(ero_cfg && rowscan_lds_bytes(c->g, dil_cfg) > kRowscanLdsMax);
+    if (park) {
+        if (!c->k1_flag) {
+            HIPCHK(c, hipMalloc((void **)&c->k1_flag, 64));
+            HIPCHK(c, hipMemset(c->k1_flag, 0, 64));
+        }
+        ++c->k1_ticket;
+        HIPCHK(c, hipStreamWriteValue32(A, c->k1_flag, c->k1_ticket, 0));      // behind the step's per-pixel launch(es)
+    }
 
     // The paired back half: both frames of a two-frame step go through ONE row-scan launch and ONE k_blob_lds launch (grid z =
     // frame) on ONE B stream behind one wait, one ring event covers both results -- 6 runtime calls a step instead of 10.
     // Small frames are bound by exactly those calls (one 1080p stream: 30 us of per-pixel kernel a step under ~40 us of
     // HIP calls).  Steps alternate between B0 / B1 with two scratch sets each, so consecutive steps' back halves overlap.
     // Speculative mode only (row scan + LDS kernel; a declined frame is repaired from its threshold bits as on the other paths).
-    const int ero_cfg = c->cfg.erode > 1 ? c->cfg.erode : 0, dil_cfg = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
     const bool paired = nj == 2 && !early && c->pair_back && c->lds_spec && !c->kal_on && !c->serial && !c->use_graph && !(c->expt & 1) &&
                         c->nb >= 2 && c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 &&
                         !(ero_cfg && rowscan_lds_bytes(c->g, dil_cfg) > kRowscanLdsMax);
@@ -1606,7 +1633,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             ProfStep *pb = i == 0 ? ps : nullptr;
             BlobBuffers &bb = c->bb[q];
             // ---- B0 / B1: the frame's row scan, behind the step's per-pixel kernel and the last reader of scratch set q ----
-            HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
+            if (!park) HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
             if (c->ev_blob_valid[q]) HIPCHK(c, hipStreamWaitEvent(R, c->ev_blob[q], 0));
             if (pb) HIPCHK(c, hipEventRecord(pb->e[2], R));
             const u64 *src = thr_buf(c, slot);
@@ -1622,7 +1649,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->last_fin = bb.fin;
             unsigned ticket = ++c->bh_ticket[q];
             if (!ticket) ticket = ++c->bh_ticket[q];
-            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
+            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R, park ? c->k1_flag : nullptr, c->k1_ticket, c->rs_park);
             bbs[i] = bb; res[i] = c->res_dev + (size_t)slot * n; tk[i] = ticket;
             c->slot_spec[slot] = 1;
             c->slot_q[slot] = 4;                         // a repair redoes the frame in scratch set 4 ...

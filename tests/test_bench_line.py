@@ -125,3 +125,27 @@ def test_gpus_must_match_the_launchers_world():
     r = _run(["--gpus", "2", "--quick", "--steps", "5"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "refusing to run a mislabelled job" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_hanging_scatter_leg_costs_the_run_that_block_not_its_line(tmp_path):
+    """bench.scatter_with_watchdog: the scatter leg runs last; should its transport hang, rank 0 prints the line it already has
+    (scatter_ingest marked "timeout") and the rank ends with rc 0 instead of sitting in a collective until the job is killed."""
+    code = r"""
+import json, sys, time, types
+sys.path.insert(0, %r)
+import bench
+bench.DETAIL_PATH = %r
+bench.scatter_leg = lambda *a, **k: time.sleep(30)
+full = json.load(open(%r))
+full["n_gpus"] = 2
+args = types.SimpleNamespace(scatter_timeout=0.5, workload="vga1", backend="gloo", scatter_steps=8)
+bench.scatter_with_watchdog(args, 2, 0, None, None, full, time.perf_counter())
+print("NOT REACHED")
+""" % (ROOT, str(tmp_path / "d.json"), os.path.join(ROOT, "tests", "golden", "bench_full_r04_sample.json"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j["scatter_ingest"]["parity"] == "timeout" and j["n_gpus"] == 2 and j["value"] > 0
+    assert "given up" in r.stderr
