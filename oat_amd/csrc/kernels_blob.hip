@@ -192,41 +192,15 @@ extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(lon
 // launch (launch_blob_pair: a launch is ~4 us of host time, and small frames are bound by exactly that).
 template <bool ERODE>
 __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *src0, const u64 *src1, int ero_k, int dil_k, BlobBuffers b0,
-                                                        BlobBuffers b1, int first_stream, int clear_lds_ok, unsigned tag,
-                                                        const unsigned *k1_flag, unsigned k1_ticket)
+                                                        BlobBuffers b1, int first_stream, int clear_lds_ok, unsigned tag)
 {
     extern __shared__ u64 er[];
     constexpr int WAVES = kRsWaves, ROWS = kRsRows;
     const bool second = blockIdx.z != 0;
     const BlobBuffers &b = second ? b1 : b0;
     const u64 *src_all = second ? src1 : src0;
-    // The parked form (k1_flag): the launch is dispatched AHEAD of the per-pixel launch that writes its source mask, with a
-    // few persistent workgroups a stream (gridDim.x < row groups), which take their wave slots while the device still has
-    // them, wait -- one lane polls between s_sleeps, the others sit in the barrier -- until the stream memory operation behind
-    // that launch has raised *k1_flag to k1_ticket, and then walk the frame's row groups gridDim.x apart.
-    if (k1_flag) {
-        __shared__ int rs_wait_failed;
-        if (threadIdx.x == 0) {
-            int bad = 0;
-            const long long t0 = wall_clock64();
-            while ((int)(__hip_atomic_load(k1_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k1_ticket) < 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > 10000000ll) { bad = 1; break; }       // 100 ms of the 100 MHz wall clock
-            }
-            rs_wait_failed = bad;
-        }
-        __syncthreads();
-        if (rs_wait_failed) {
-            if (threadIdx.x == 0) atomicOr(&b.rs_bad[first_stream + blockIdx.y], 1u);
-            return;
-        }
-        // this workgroup was resident BEFORE its source mask was written: whatever its compute unit's L1 and its XCD's L2 hold of
-        // that ring slot's buffer is from eight frames ago
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    const int ngroups = (g.H + ROWS - 1) / ROWS;
-#pragma unroll 1
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int grp = blockIdx.x;                  // row group of this workgroup
+    {
 #ifdef OATGPU_RS_TIMING
     const long long rs_t0 = wall_clock64();
 #endif
@@ -372,7 +346,6 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
 #else
     (void)tag;
 #endif
-    if (ERODE) __syncthreads();            // (persistent form: the next row group's erosion rewrites the LDS rows)
     }
 }
 
@@ -383,18 +356,15 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k)
 
 // src / b: nf (1 or 2) frames' source masks and scratch sets
 static void launch_rowscan(const Geom &g, const u64 *const *src, int ero_k, int dil_k, const BlobBuffers *b, int nf, int first_stream,
-                           int n_streams, int clear, hipStream_t st, unsigned tag = 0u, const unsigned *k1_flag = nullptr,
-                           unsigned k1_ticket = 0u, int park_groups = 0)
+                           int n_streams, int clear, hipStream_t st, unsigned tag = 0u)
 {
     const int k = nf > 1 ? 1 : 0;
-    const int groups = (g.H + kRsRows - 1) / kRsRows;
-    const dim3 grid(k1_flag && park_groups > 0 && park_groups < groups ? park_groups : groups, n_streams, nf), block(64 * kRsWaves);
+    const dim3 grid((g.H + kRsRows - 1) / kRsRows, n_streams, nf), block(64 * kRsWaves);
     if (ero_k > 1)
         hipLaunchKernelGGL(k_rowscan<true>, grid, block, rowscan_lds_bytes(g, dil_k), st, g, src[0], src[k], ero_k, dil_k, b[0], b[k],
-                           first_stream, clear, tag, k1_flag, k1_ticket);
+                           first_stream, clear, tag);
     else
-        hipLaunchKernelGGL(k_rowscan<false>, grid, block, 0, st, g, src[0], src[k], 0, dil_k, b[0], b[k], first_stream, clear, tag,
-                           k1_flag, k1_ticket);
+        hipLaunchKernelGGL(k_rowscan<false>, grid, block, 0, st, g, src[0], src[k], 0, dil_k, b[0], b[k], first_stream, clear, tag);
 }
 
 // ------------------------------------------------------------ union-find -----
@@ -1256,20 +1226,16 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
 // end-of-kernel release make its output visible to agent-scope loads, one lane per stream publishes.  (The in-kernel
 // form -- k_rowscan storing what k_blob_lds reads write-through and its last-arriving workgroup publishing the ticket --
 // saved that launch and cost the per-pixel kernel 3-4 %: profiles/r04o_*, r04p_*.)
-// (rs_bad: a parked row scan that gave up waiting for its per-pixel launch publishes NOTHING -- the blob workgroup then times
-// out and declines the frame to the global kernels -- and is cleared for the scratch set's next frame)
-__global__ void k_publish_ticket(unsigned *ready, unsigned *rs_bad, int first_stream, unsigned ticket)
+__global__ void k_publish_ticket(unsigned *ready, int first_stream, unsigned ticket)
 {
-    const int s = first_stream + threadIdx.x;
-    if (__hip_atomic_load(&rs_bad[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { rs_bad[s] = 0u; return; }
-    __hip_atomic_store(&ready[s], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ready[first_stream + threadIdx.x], ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st, const unsigned *k1_flag, unsigned k1_ticket, int park_groups)
+                           int n_streams, unsigned ticket, hipStream_t st)
 {
-    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, 0, st, ticket, k1_flag, k1_ticket, park_groups);
+    launch_rowscan(g, &src_bits, ero_k, dil_k, &b, 1, first_stream, n_streams, 0, st, ticket);
     for (int s0 = 0; s0 < n_streams; s0 += 1024)
-        hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready, b.rs_bad,
+        hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(n_streams - s0 < 1024 ? n_streams - s0 : 1024), 0, st, b.ready,
                            first_stream + s0, ticket);
 }
 

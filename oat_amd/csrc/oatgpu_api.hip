@@ -111,11 +111,6 @@ struct oatgpu_ctx {
     int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
     bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
-    int rs_park = 0;                 // early order: persistent row-scan workgroups a stream, parked ahead of their per-pixel launch (0: off;
-                                     // measurement builds: OATGPU_RS_PARK=n)
-    unsigned *k1_flag = nullptr;     // device word the per-pixel stream raises behind every step's launch (hipStreamWriteValue32)
-    unsigned k1_ticket = 0;
-    int early_sets = 4;              // scratch sets the early order cycles through (measurement builds: OATGPU_EARLY_SETS=2, the r04-r06 layout)
     int nsets = 0;                   // scratch sets allocated (nb with the context; 4 once the paired back half has run)
     int pair_back = 1;               // two-frame steps outside the early order: ONE row-scan launch and ONE blob launch for both frames
                                      // (measurement builds: OATGPU_PAIR_BACK=0)
@@ -393,7 +388,6 @@ static void free_all(oatgpu_ctx *c)
     hipFree(c->bb[0].thr);
     hipFree(c->kal.state);
     hipFree(c->audit_dev);
-    hipFree(c->k1_flag);
     hipFree(c->wild_sink);
     hipFree(c->frames_ring);
     if (c->ev_in) hipEventDestroy(c->ev_in);
@@ -405,7 +399,7 @@ static void free_all(oatgpu_ctx *c)
         hipFree(b.tmp); hipFree(b.morph); hipFree(b.fin); hipFree(b.trans);
         hipFree(b.carry); hipFree(b.parent); hipFree(b.acc); hipFree(b.done);
         hipFree(b.roots); hipFree(b.nroots); hipFree(b.wpre); hipFree(b.rowinfo); hipFree(b.lds_ok);
-        hipFree(b.ready); hipFree(b.rs_bad);
+        hipFree(b.ready);
     }
     if (c->res_host) hipHostFree(c->res_host);
     if (c->dens_host) hipHostFree(c->dens_host);
@@ -477,8 +471,7 @@ static bool alloc_scratch_set(oatgpu_ctx *c, int q)
     A((void **)&b.rowinfo, n * (size_t)g.H * sizeof(int));
     A((void **)&b.lds_ok, n * sizeof(unsigned));
     A((void **)&b.ready, n * sizeof(unsigned));
-    A((void **)&b.rs_bad, n * sizeof(unsigned));
-    for (unsigned *p : {b.done, b.nroots, b.lds_ok, b.ready, b.rs_bad})
+    for (unsigned *p : {b.done, b.nroots, b.lds_ok, b.ready})
         if (ok && hipMemsetAsync(p, 0, n * sizeof(unsigned), c->stream) != hipSuccess) ok = false;
     return ok;
 }
@@ -564,8 +557,6 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
-    if (const char *e = measure_env("OATGPU_RS_PARK")) c->rs_park = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char *e = measure_env("OATGPU_EARLY_SETS")) c->early_sets = atoi(e) == 2 ? 2 : 4;
     if (const char *e = measure_env("OATGPU_PAIR_BACK")) c->pair_back = atoi(e) != 0;
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
@@ -1557,16 +1548,6 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
 
     if (k1_done && !k1_done_recorded) HIPCHK(c, hipEventRecord(k1_done, A));
     const int ero_cfg = c->cfg.erode > 1 ? c->cfg.erode : 0, dil_cfg = c->cfg.dilate > 1 ? c->cfg.dilate : 0;
-    const bool park = early && c->rs_park > 0 && !(ero_cfg && rowscan_lds_bytes(c->g, dil_cfg) > kRowscanLdsMax);
-    if (park) {
-        if (!c->k1_flag) {
-            HIPCHK(c, hipMalloc((void **)&c->k1_flag, 64));
-            HIPCHK(c, hipMemset(c->k1_flag, 0, 64));
-        }
-        ++c->k1_ticket;
-        HIPCHK(c, hipStreamWriteValue32(A, c->k1_flag, c->k1_ticket, 0));      // behind the step's per-pixel launch(es)
-    }
-
     // The paired back half: both frames of a two-frame step go through ONE row-scan launch and ONE k_blob_lds launch (grid z =
     // frame) on ONE B stream behind one wait, one ring event covers both results -- 6 runtime calls a step instead of 10.
     // Small frames are bound by exactly those calls (one 1080p stream: 30 us of per-pixel kernel a step under ~40 us of
@@ -1627,13 +1608,13 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             // (~30 us) per step, as long as the per-pixel kernel's own period: the row scan started 37 us behind its per-pixel
             // launch, a result was ready ~125 us behind it (profiles/r07f_timeline_rowscan_shapes.txt).  With four, a step's row
             // scans depend on nothing but their own per-pixel launch.
-            const int slot = j[i].slot, q = (int)(c->early_frames++ & (unsigned)(c->early_sets - 1));
+            const int slot = j[i].slot, q = (int)(c->early_frames++ & 3u);
             qs[i] = q;
             hipStream_t R = c->stream_b[q & 1];
             ProfStep *pb = i == 0 ? ps : nullptr;
             BlobBuffers &bb = c->bb[q];
             // ---- B0 / B1: the frame's row scan, behind the step's per-pixel kernel and the last reader of scratch set q ----
-            if (!park) HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
+            HIPCHK(c, hipStreamWaitEvent(R, k1_done, 0));
             if (c->ev_blob_valid[q]) HIPCHK(c, hipStreamWaitEvent(R, c->ev_blob[q], 0));
             if (pb) HIPCHK(c, hipEventRecord(pb->e[2], R));
             const u64 *src = thr_buf(c, slot);
@@ -1649,7 +1630,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
             c->last_fin = bb.fin;
             unsigned ticket = ++c->bh_ticket[q];
             if (!ticket) ticket = ++c->bh_ticket[q];
-            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R, park ? c->k1_flag : nullptr, c->k1_ticket, c->rs_park);
+            launch_rowscan_signal(g, bb, src, ero, dil, 0, n, ticket, R);
             bbs[i] = bb; res[i] = c->res_dev + (size_t)slot * n; tk[i] = ticket;
             c->slot_spec[slot] = 1;
             c->slot_q[slot] = 4;                         // a repair redoes the frame in scratch set 4 ...

@@ -170,9 +170,6 @@ struct BlobBuffers {
     // the early blob workgroup (kernels_blob.hip "Early dispatch"): a one-lane kernel behind the row scan publishes the frame's
     // ticket, the k_blob_lds workgroup that was dispatched ahead of it waits for exactly that ticket
     unsigned *ready;       // [n]          ticket of the latest frame whose row scan is complete (k_publish_ticket)
-    // the parked row scan (k_rowscan with a per-pixel-launch ticket): nonzero = a workgroup gave up waiting for its launch;
-    // k_publish_ticket then publishes nothing and the frame's blob workgroup declines it to the global kernels
-    unsigned *rs_bad;      // [n]
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -223,11 +220,8 @@ void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int e
 // The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan with a one-lane kernel behind
 // it that publishes `ticket`, and everything behind the row scan, whose k_blob_lds workgroup may be dispatched long before
 // the row scan has run and waits for `ticket` on the device.  ticket != 0.
-// k1_flag != nullptr: the PARKED form -- park_groups persistent workgroups a stream, dispatched ahead of the per-pixel launch
-// that produces src_bits, wait on the device until *k1_flag has reached k1_ticket (hipStreamWriteValue32 behind that launch)
 void launch_rowscan_signal(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, int first_stream,
-                           int n_streams, unsigned ticket, hipStream_t st, const unsigned *k1_flag = nullptr, unsigned k1_ticket = 0u,
-                           int park_groups = 0);
+                           int n_streams, unsigned ticket, hipStream_t st);
 // both frames of a two-frame step: ONE row-scan launch and ONE k_blob_lds launch (speculative mode), lds-able geometries only
 void launch_blob_pair(const Geom &g, const BlobBuffers *b, const u64 *const *src, int ero_k, int dil_k, double min_area,
                       double max_area, ResultRec *const *results, int n_streams, hipStream_t st);
