@@ -8,7 +8,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_default
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_default -o r -- python $R/bench.py --no-pmc > $O/${TAG}_bench_default_traced.json 2> /tmp/kt_default.err
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_default -o r -- python $R/bench.py --no-pmc --detail-out $O/${TAG}_bench_default_traced.json > $O/${TAG}_bench_default_traced.line 2> /tmp/kt_default.err
 db=$(find /tmp/kt_default -name "*.db" | head -1)
 python - "$db" "$O/${TAG}_bench_default_traced.json" > $O/${TAG}_trace_default.md <<'PY'
 import json, sqlite3, sys
@@ -32,7 +32,7 @@ print("|---|---|---|---|---|---|---|---|---|")
 for (name, gx, gy), d in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     q = sorted(d)
     print(f"| `{name}` | ({gx}, {gy}) | {len(d)} | {sum(d)/len(d):.1f} | {q[len(q)//2]:.1f} | {q[len(q)//10]:.1f} | {q[(9*len(q))//10]:.1f} | {min(d):.1f} | {max(d):.1f} |")
-j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+j = json.load(open(sys.argv[2]))          # the run's bench_detail (--detail-out): everything it measured
 r = j["roofline"]
 print()
 print("The line this traced run printed (HIP events on the kernel's own stream):")

@@ -1936,3 +1936,98 @@ def test_device_count_and_numa_node(A):
     if node >= 0:
         assert os.path.exists(f"/sys/devices/system/node/node{node}/cpulist")
     assert lib.oatgpu_device_numa_node(n + 5) == -1
+
+
+@pytest.mark.parametrize("ring", [2, 3, 5, 8])
+@pytest.mark.parametrize("geom", [(96, 200, 3), (480, 640, 1)])
+def test_paired_back_half_equals_one_frame_a_launch_and_the_oracle(A, ring, geom):
+    """Round 5: outside the early order both frames of a two-frame step share ONE row-scan launch and ONE k_blob_lds launch
+    (grid z = frame; steps alternate between two B streams with two scratch sets each).  Quiet and BUSY frames (busy = the LDS
+    kernel declines the frame -> repaired by the global kernels in the frame's own scratch set; then the plain order until
+    the streak is back -> a switch of paths with a drain), even and odd ring depths, one and several streams, an odd number of
+    frames (the last one goes out alone): every result equals one frame a launch (the per-frame plain order) and the oracle;
+    the step shape query says what ran."""
+    import torch
+    rows, cols, n = geom
+    rng = np.random.default_rng(ring * 7 + n)
+    win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
+    kw = dict(n_streams=n, ring_depth=ring, adaptation_coeff=0.01, erode=3, dilate=5, area=(8.0, 1e6), **win)
+    hp, ref = A.HotPath(rows, cols, **kw), A.HotPath(rows, cols, **kw)
+    hp.set_fusion(2)
+    ref.set_fusion(1)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=8.0, max_area=1e6)
+    orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
+    base = rng.integers(90, 150, (n, rows, cols, 3)).astype(np.int16)
+
+    def frame(t, busy):
+        f = np.clip(base + rng.integers(-5, 6, base.shape), 0, 255).astype(np.uint8)
+        if t > 0:
+            for s_ in range(n):
+                cy, cx = 8 + (7 * t + 11 * s_) % (rows - 40), 9 + (11 * t + 17 * s_) % (cols - 60)
+                f[s_, cy:cy + 14, cx:cx + 21] = (255, 64, 0)
+                if busy:                                             # specks of the blob colour: far more runs than the LDS kernel takes
+                    f[s_][rng.random((rows, cols)) < (0.25 if rows < 200 else 0.02)] = (255, 64, 0)
+        return f
+    pattern = [0] * 6 + [1, 0, 0, 1, 1, 0] + [0] * 19 + [1] + [0] * 4        # 31 frames: odd
+    frames = [frame(t, b) for t, b in enumerate(pattern)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+
+    def run(h):
+        out = []
+        for d in dev:
+            h.enqueue_dev(d.data_ptr(), keepalive=d)
+            if h.outstanding() >= ring:
+                out.append(h.collect())
+        while h.outstanding():
+            out.append(h.collect())
+        return out
+    got, plain = run(hp), run(ref)
+    assert len(got) == len(frames) and got == plain
+    for t, f in enumerate(frames):
+        for s_ in range(n):
+            _same_detection(got[t][s_], O.chain_step(orc[s_], f[s_], 0.01, p)[0], (t, s_, pattern[t]))
+    for s_ in range(n):
+        assert (hp.read_mask(A.ffi.TAP_MORPH, s_) == ref.read_mask(A.ffi.TAP_MORPH, s_)).all()
+        assert (hp.read_mask(A.ffi.TAP_FINAL, s_) == ref.read_mask(A.ffi.TAP_FINAL, s_)).all()
+        _same_state(hp.mog_state(s_), orc[s_].state(), s_)
+    wg, early = hp.last_step_shape()
+    assert wg in (64, 256) and early is False                       # (well below 4 MP a step: never the early order)
+    assert hp.early_blob_timeouts() == 0
+    hp.close(); ref.close()
+
+
+def test_abi8_plumbing_k1_workgroup_latency_sequence_and_open_retries(A):
+    """oatgpu_set_k1_workgroup (results identical whatever the workgroup size; oatgpu_last_step_shape reports it),
+    oatgpu_track_sequence_dev_latency (hand-over before collection, both ascending), oatgpu_device_open_retries."""
+    import ctypes as C
+    import torch
+    rows, cols = 120, 256
+    from oat_amd.synth import SyntheticStream, disc_hsv_window
+    st = SyntheticStream(rows, cols, 5, n_discs=1, radius=9)
+    frames = [torch.from_numpy(st.frame(t, with_discs=t > 0)[None].copy()).cuda() for t in range(21)]
+    torch.cuda.synchronize()
+    outs = []
+    for wg in (0, 64, 256):
+        hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+        hp.set_k1_workgroup(wg)
+        res = hp.track_sequence_dev([f.data_ptr() for f in frames])
+        outs.append([(r[0].position_valid, r[0].a00, r[0].a10, r[0].a01, r[0].first_pixel) for r in res])
+        if wg:
+            assert hp.last_step_shape()[0] == wg
+        hp.close()
+    assert outs[0] == outs[1] == outs[2] and sum(o[0] for o in outs[0]) >= 15
+    hp = A.HotPath(rows, cols, n_streams=1, ring_depth=4, adaptation_coeff=0.01, erode=3, dilate=5, area=(5.0, 1e5), **disc_hsv_window())
+    with pytest.raises(A.ffi.OatGpuError):
+        hp.set_k1_workgroup(128)
+    n = len(frames)
+    arr = (C.c_void_p * n)(*[f.data_ptr() for f in frames])
+    out = (A.ffi.Position * n)()
+    done, enq = (C.c_double * n)(), (C.c_double * n)()
+    A.ffi.check(hp.lib, hp.ctx, hp.lib.oatgpu_track_sequence_dev_latency(hp.ctx, arr, n, 0.01, out, done, enq))
+    d, e = list(done), list(enq)
+    assert all(e[i] <= d[i] for i in range(n)) and d == sorted(d) and e == sorted(e) and e[0] >= 0.0
+    assert all(e[i + 4] >= d[i] for i in range(n - 4))              # ring depth 4: frame i + 4 is handed over after frame i was collected
+    assert [(o.valid, o.a00) for o in out] == [(v, a) for v, a, *_ in outs[0]]
+    assert hp.lib.oatgpu_device_open_retries() == 0
+    hp.close()
