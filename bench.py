@@ -1308,7 +1308,7 @@ def main():
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: skip the scatter_ingest leg (frames from rank 0 through "
                                                               "the stream->rank scatter)")
     ap.add_argument("--scatter-steps", type=int, default=200, help="steps of the scatter_ingest leg (N > 1)")
-    ap.add_argument("--scatter-timeout", type=float, default=300.0, help="seconds after which a hanging scatter leg is given up")
+    ap.add_argument("--scatter-timeout", type=float, default=150.0, help="seconds after which a hanging scatter leg is given up")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
