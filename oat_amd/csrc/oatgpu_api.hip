@@ -112,6 +112,10 @@ struct oatgpu_ctx {
     bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
     int nsets = 0;                   // scratch sets allocated (nb with the context; 4 once the paired back half has run)
+    int lone_plain = 1;              // a frame launched with NOTHING else outstanding (a camera-paced caller) takes the plain order even where the early
+                                     // order is the default: no ticket kernel, no parked workgroup to release -- one frame at a time 133.5 -> 129.3 us at
+                                     // 4K, 89.6 -> 85.9 us for two 1080p streams, frame rate unchanged (profiles/r07t_lone_frame_plain_order_ab.txt;
+                                     // measurement builds: OATGPU_LONE_PLAIN=0)
     int pair_back = 1;               // two-frame steps outside the early order: ONE row-scan launch and ONE blob launch for both frames
                                      // (measurement builds: OATGPU_PAIR_BACK=0)
     unsigned pair_steps = 0;         // paired steps so far (their parity picks the B stream and the two scratch sets)
@@ -557,6 +561,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
         ok = hipEventCreateWithFlags(&c->ev_blob[q], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     if (const char *e = measure_env("OATGPU_EARLY_BLOB")) c->early_blob = atoi(e);
     if (const char *e = measure_env("OATGPU_EARLY_MIN_PX")) c->early_min_px = (size_t)atoll(e);
+    if (const char *e = measure_env("OATGPU_LONE_PLAIN")) c->lone_plain = atoi(e) != 0;
     if (const char *e = measure_env("OATGPU_PAIR_BACK")) c->pair_back = atoi(e) != 0;
     if (const char *e = measure_env("OATGPU_K1_WG")) { const int v = atoi(e); if (v == 64 || v == 256) c->k1_wg_force = v; }
 
@@ -1440,7 +1445,7 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
 
 // The kernels of one frame (nj == 1) or of two consecutive frames (nj == 2: K1 once for both where the streams'
 // learning-rate schedules allow, then each frame's back half on its own B stream).
-static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
+static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, bool lone = false)
 {
     const int n = c->cfg.n_streams;
     hipStream_t A = c->stream;
@@ -1490,14 +1495,14 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj)
     // ... and only while frames go through the LDS kernel alone (kBlobSpec): a step in the full launch sequence -- the position
     // filter is on, or a frame was declined a moment ago -- takes the plain order (the switch drains the B streams)
     const bool early_wanted = c->early_blob < 0 ? n <= 3 : c->early_blob != 0;        // (r06a / r06e: 2 x 1080p 64.8 k -> 70.3 k fps, 3 x: 69.3 k -> 72-74 k, 4 x: 73.0 k -> 65-72 k)
-    const bool early = early_wanted && !c->early_off && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
+    const bool early = early_wanted && !(lone && c->lone_plain) && !c->early_off && c->lds_spec && !c->kal_on && !j[0].ready && !share_b && c->nb >= 3 && !c->serial && !c->use_graph && !(c->expt & 1) &&
                        c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 && (size_t)n * (size_t)c->g.P >= c->early_min_px;
     // Threads a K1 workgroup (kernels_mog.hip, k_mog_fused): one wave a workgroup keeps every wave slot filled (K1 -3.5 % on
     // an everyday 4K model, -5.5 % on a dense one) and starves the back half's workgroups of slots.  Taken where that
     // does not come back as a lower frame rate: steps whose blob workgroup is already resident (early), and dense models
     // (streaming-load launches: K1 is 5-10 x the back half, 4K 6 670 -> 7 110 fps, profiles/r05n_dense_wg64_ab.txt; a result
     // is then ready ~230 us later, one K1 launch, because the blob workgroup gets in when the launch drains).
-    const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads) ? 64 : 256;
+    const int k1_wg = c->k1_wg_force ? c->k1_wg_force : (early || c->nt_loads || (lone && c->lone_plain && early_wanted && (size_t)n * (size_t)c->g.P >= c->early_min_px)) ? 64 : 256;
     c->last_k1_wg = k1_wg;
     c->last_step_early = early;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
@@ -1709,7 +1714,7 @@ static int flush_pending(oatgpu_ctx *c)
     if (!c->pend_valid) return OATGPU_OK;
     c->pend_valid = false;
     int rc = hipSetDevice(c->cfg.device) == hipSuccess ? OATGPU_OK : fail(c, OATGPU_E_HIP, "hipSetDevice(%d) failed", c->cfg.device);
-    if (!rc) rc = launch_jobs(c, &c->pend, 1);
+    if (!rc) rc = launch_jobs(c, &c->pend, 1, c->ring_count == 1);        // (lone: nothing else is outstanding)
     if (rc) {
         // the same rule as in enqueue_frames: mog_begin has advanced the frame counts and the rate schedule, the model may
         // have moved -- fatal for the context.  The registered frame is no longer outstanding: without this a later collect
@@ -1753,7 +1758,7 @@ static int enqueue_frames(oatgpu_ctx *c, const void *frames_dev, double lr, hipE
         c->pend = cur;
         c->pend_valid = true;
     } else {
-        rc = launch_jobs(c, &cur, 1);
+        rc = launch_jobs(c, &cur, 1, c->ring_count == 0);
     }
     if (rc) {
         // launch_jobs had advanced the streams' frame counts and rate schedules (mog_begin) and may have updated the
