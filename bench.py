@@ -252,9 +252,10 @@ def open_device_with_retry(dev, rank, attempts=6):
         try:
             torch.cuda.set_device(dev)
             torch.empty(8, device=dev)       # an allocation creates the context.  NOT a kernel plus a read-back: `.sum().item()`
-            torch.cuda.synchronize(dev)      # here made the runtime set up its device-to-host path before the library created its
-            return n                         # four streams, which then shared hardware queues (oatgpu_api.hip "The HIP streams"):
-                                             # vga1 78 k -> 48 k fps, one 1080p stream 50 k -> 40 k (profiles/r07b_small_workloads_vs_r04.txt)
+            torch.cuda.synchronize(dev)      # here, before the process was pinned and the library had made its streams, cost the
+            return n                         # host-bound workloads 20-40 % with identical kernel durations (vga1 78 k -> 48 k fps, one
+                                             # 1080p stream 50 k -> 40 k: profiles/r07b_small_workloads_vs_r04.txt, r07d_...; mechanism
+                                             # not established -- the library's streams do run side by side either way, r07v / r07w)
         except Exception as e:
             n += 1
             log(f"[rank {rank}] opening {dev} failed (attempt {a + 1}/{attempts}): {type(e).__name__}: {str(e)[-300:]}")
