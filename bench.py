@@ -993,12 +993,14 @@ def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_sta
     import threading
     done = threading.Event()
 
-    def fire():
+    def fire(why=None):
         if done.is_set():
             return
-        log(f"[rank {rank}] scatter leg: no result within {args.scatter_timeout} s -- given up")
+        done.set()
+        why = why or f"no result within {args.scatter_timeout} s"
+        log(f"[rank {rank}] scatter leg: {why} -- given up")
         if rank == 0 and line_so_far is not None:
-            line_so_far["scatter_ingest"] = dict(error=f"no result within {args.scatter_timeout} s", parity="timeout",
+            line_so_far["scatter_ingest"] = dict(error=why, parity="timeout" if "within" in why else "error",
                                                  backend=args.backend)
             line_so_far["bench_wall_s"] = time.perf_counter() - t_start
             emit(line_so_far)
@@ -1008,6 +1010,13 @@ def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_sta
     t = threading.Timer(args.scatter_timeout, fire)
     t.daemon = True
     t.start()
+    # (a peer that DIES in the leg makes the launcher terminate the others: rank 0 then still hands over the line it has)
+    import signal
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, lambda *_: fire("terminated by the launcher (a peer died in the scatter leg)"))
+    except ValueError:
+        pass
     try:
         sc = scatter_leg(args.workload, world, rank, dev, args.backend, args.scatter_steps, reduce_max)
     except Exception as e:
@@ -1015,6 +1024,8 @@ def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_sta
         sc = dict(error=str(e)[-200:], parity="error", backend=args.backend)
     done.set()
     t.cancel()
+    if old_term is not None:
+        signal.signal(signal.SIGTERM, old_term)
     return sc
 
 
