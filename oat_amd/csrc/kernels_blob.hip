@@ -171,6 +171,10 @@ __device__ __forceinline__ u64 dilate_word_lds(const Geom &g, const u64 *er, int
 // say where the 55-60 us of this kernel beside the per-pixel kernel go: a workgroup RUNS 7 us (9 p90), the 540 workgroups of a 4K
 // frame START over 35 us -- the dispatcher hands this queue ~15 workgroups a microsecond while the per-pixel launch streams
 // 1 300 a microsecond through the other.
+// (Rows a workgroup: 8 / 16 instead of 4 -- fewer workgroups beside K1, a longer loop in each -- is a trade, not a gain: 4K
+// 19.0 k -> 19.3 k / 19.6 k fps and one 1080p stream 56.2 k -> 56.8 k / 58.9 k, because K1 is disturbed less, but a frame's
+// result comes 40 / 83 us later (gpu_total 242 -> 282 / 325 us) and one frame at a time takes 127 -> 131 / 141 us:
+// profiles/r07y_rowscan_rows_per_workgroup_ab.txt.  Oat is a real-time tracker: four rows.)
 constexpr int kRsWaves = 4, kRsRows = 4;
 
 #ifdef OATGPU_RS_TIMING             // measurement builds only (make variant DEFS=-DOATGPU_RS_TIMING, tools/rowscan_probe.py)
