@@ -111,7 +111,7 @@ struct oatgpu_ctx {
     int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
     bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
-    int nsets = 0;                   // scratch sets allocated (nb with the context; 4 once the paired back half has run)
+    bool have_set[kSets] = {};       // scratch sets allocated: 0 .. nb-1 with the context, the others on first use
     int lone_plain = 1;              // a frame launched with NOTHING else outstanding (a camera-paced caller) takes the plain order even where the early
                                      // order is the default: no ticket kernel, no parked workgroup to release -- one frame at a time 133.5 -> 129.3 us at
                                      // 4K, 89.6 -> 85.9 us for two 1080p streams, frame rate unchanged (profiles/r07t_lone_frame_plain_order_ab.txt;
@@ -577,7 +577,7 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // i.e. after the back half that read its buffer has finished -- stream A never waits for a B stream.
     A((void **)&c->bb[0].thr, (size_t)c->ring_slots * n * NW * 8);
     for (int q = 0; q < c->nb && ok; ++q) ok = alloc_scratch_set(c, q);
-    c->nsets = c->nb;
+    for (int q = 0; q < c->nb && ok; ++q) c->have_set[q] = true;
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
@@ -1557,18 +1557,25 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
     // frame) on ONE B stream behind one wait, one ring event covers both results -- 6 runtime calls a step instead of 10.
     // Small frames are bound by exactly those calls (one 1080p stream: 30 us of per-pixel kernel a step under ~40 us of
     // HIP calls).  Steps alternate between B0 / B1 with two scratch sets each, so consecutive steps' back halves overlap.
-    // Speculative mode only (row scan + LDS kernel; a declined frame is repaired from its threshold bits as on the other paths).
+    // Speculative mode only (row scan + LDS kernel; a declined frame is repaired from its threshold bits in the repair set, below).
     const bool paired = nj == 2 && !early && c->pair_back && c->lds_spec && !c->kal_on && !c->serial && !c->use_graph && !(c->expt & 1) &&
-                        c->nb >= 2 && c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 &&
+                        c->nb >= 3 && c->g.H > 2 && c->g.H <= 16383 && c->g.W <= 16383 &&
                         !(ero_cfg && rowscan_lds_bytes(c->g, dil_cfg) > kRowscanLdsMax);
     const int path = early ? 1 : paired ? 2 : 0;
     if (c->last_early >= 0 && c->last_early != path)          // the paths use the scratch sets from different streams
         for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     c->last_early = path;
-    for (int q = c->nsets; q < (early ? 5 : paired ? 4 : 0); ++q) {           // first use: the scratch sets beyond the context's nb
+    // Scratch sets beyond the context's nb, on first use: 3 for the early and the paired layout; 4 = THE REPAIR SET -- every frame that
+    // goes through the LDS kernel alone (kBlobSpec), on whichever path, is repaired in set 4 on B2 if it is declined: each layout
+    // ties its sets to streams in its own way (plain: set q on stream q; paired: sets 2p, 2p + 1 on stream p; early: sets 0..3 on
+    // B0 / B1 by parity), a switch of layouts drains the streams, but a repair comes LATER -- at the frame's collect -- and must
+    // not write a set that the layout of the day uses from another stream.
+    const bool spec_plain = !early && !paired && c->lds_spec && !c->kal_on && !c->use_graph && !(c->expt & 1) && c->nb >= 3;
+    for (int q = 3; q < oatgpu_ctx::kSets; ++q) {
+        if (c->have_set[q] || !(q == 3 ? (early || paired) : (early || paired || spec_plain))) continue;
         if (!alloc_scratch_set(c, q)) return fail(c, OATGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->nsets = q + 1;
+        c->have_set[q] = true;
     }
     if (paired) {
         const Geom &g = c->g;
@@ -1586,8 +1593,13 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
         for (int i = 0; i < 2; ++i) {
             const int slot = j[i].slot;
             c->slot_spec[slot] = 1;
-            c->slot_q[slot] = (char)(2 * p + i);          // a repair redoes the frame in its own scratch set ...
-            c->slot_st[slot] = (char)p;                   // ... on its step's B stream, behind whatever that is busy with
+            // A repair redoes the frame in scratch set 4 on B2, like the early order's -- NOT in the frame's own set on its step's
+            // stream: this layout ties set 2p + i to stream p, the plain order ties set q to stream q, and a repair launched
+            // after a switch to the plain order (the decline itself causes one) would write set 1 from B0 while a plain frame
+            // uses it from B1 (found by tools/fuzz.py --seed 11, configuration 301: profiles/r07_fuzz_1500.txt).  Set 4 is
+            // touched by repairs only, and only from B2.
+            c->slot_q[slot] = 4;
+            c->slot_st[slot] = 2;
             c->slot_filtered[slot] = 0;
             c->slot_ev[slot] = j[1].slot;                 // one ring event behind the step's blob launch covers both results
         }
@@ -1687,8 +1699,8 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
             if (pb) HIPCHK(c, hipEventRecord(pb->e[2], B));
             const int mode = (c->lds_spec && !c->kal_on) ? kBlobSpec : kBlobFull;   // (the position filter is sequential: no repairs behind it)
             c->slot_spec[slot] = mode == kBlobSpec;
-            c->slot_q[slot] = (char)q;
-            c->slot_st[slot] = (char)q;
+            c->slot_q[slot] = (char)(spec_plain ? 4 : q);          // (a declined frame is redone in the repair set on B2, above)
+            c->slot_st[slot] = (char)(spec_plain ? 2 : q);
             int rc = back_half(c, c->bb[q], thr_buf(c, k), 0, n, slot, B, pb ? pb->e[3] : nullptr, -1, -1, mode);
             if (rc) return rc;
         }

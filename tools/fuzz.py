@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="run this configuration alone (the others still draw their random numbers) and say what differs")
     args = ap.parse_args()
     import torch
     import oat_amd
@@ -73,6 +74,8 @@ def main():
         mode = str(rng.choice(["sync", "dev", "host"]))
         frames = make_frames(rng, rows, cols, n, nframes, channels)
         restore = int(rng.integers(0, 2))          # both readings of MOG2Invoker's mode count (oracle/mog2.c)
+        if args.only >= 0 and ci != args.only:
+            continue
 
         hp = oat_amd.HotPath(rows, cols, n_streams=n, ring_depth=ring, channels=channels, adaptation_coeff=lr,
                              erode=e, dilate=d, area=area, mog_restore_nmodes=restore, **win)
@@ -123,6 +126,8 @@ def main():
                                                   (dres["a00"], dres["a10"], dres["a01"], dres["first_pixel"], dres["x"], dres["y"]))
                 if masks:
                     ok &= bool((masks[t][s] == thr).all())
+                if args.only >= 0:
+                    print(f"frame {t} stream {s}: got valid {g.position_valid} a00 {g.a00} a10 {g.a10} a01 {g.a01} first {g.first_pixel} | want {dres}")
                 checked += 1
         if not ok:
             bad += 1
