@@ -1272,6 +1272,10 @@ static void prof_fold(oatgpu_ctx *c)
         hipEventElapsedTime(&b, p.e[2], p.e[3]);   // erode (stream B)
         hipEventElapsedTime(&d, p.e[3], p.e[4]);   // dilate + labelling + sums + selection (stream B)
         hipEventElapsedTime(&t, p.e[0], p.e[4]);   // latency of the frame through both streams
+        // (a host thread descheduled between the first event's record and the launch call puts its absence INTO the event
+        // pair: one 10 ms sample among 145 turned a 100 us average into 238 us, profiles/r07z run of the driver's arguments.  A
+        // sample eight times the average of those taken so far is the host's, not the kernel's: dropped.)
+        if (c->prof_sum.steps >= 8 && a > 8.0 * (c->prof_sum.mog_ms / (double)c->prof_sum.steps)) continue;
         c->prof_sum.steps += 1;
         c->prof_sum.mog_frames += p.frames;
         c->prof_sum.mog_ms += a; c->prof_sum.morph_ms += b; c->prof_sum.blob_ms += d; c->prof_sum.total_ms += t;
