@@ -149,3 +149,15 @@ print("NOT REACHED")
     j = json.loads(lines[0])
     assert j["scatter_ingest"]["parity"] == "timeout" and j["n_gpus"] == 2 and j["value"] > 0
     assert "given up" in r.stderr
+
+
+def test_slim_line_survives_a_run_that_measured_almost_nothing():
+    """A leg that failed leaves None behind (the probes of bench.py never break the line): the builder takes any of it."""
+    full = {"metric": "m", "value": 1.0, "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1000.0,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"name": "vga1"}, "roofline": {"frac": None}, "cpu_baseline": None, "stage_ms": None, "latency_us": None,
+            "extra_workloads": {}, "pipeline": {"error": "x"}, "partition": None, "scatter_ingest": {"error": "boom", "parity": "error"}}
+    j = json.loads(json.dumps(bench.slim_line(full)))
+    assert j["value"] == 1.0 and j["roofline"]["frac"] is None and j["cpu_baseline"] is None
+    assert j["scatter_ingest"] == {"error": "boom", "parity": "error"} and j["partition"]["ranks"] == []
+    assert float("nan") != float("nan") and bench._sig(float("nan")) is None and bench._sig(float("inf")) is None
