@@ -3,7 +3,9 @@
 
     OATGPU_SETTLE_STREAMS=0|1 OATGPU_MEASURE_PY=1 OATGPU_LIB=build/variants/liboatgpu_meas.so python tools/stream_settle_probe.py clean|readback WORKLOAD
 
-readback: `torch.zeros(8, device=...).sum().item()` first -- what cost one 1080p stream 20 % and a 640 x 480 stream 40 % in r07b."""
+readback: `torch.zeros(8, device=...).sum().item()` first -- what cost one 1080p stream 20 % and a 640 x 480 stream 40 % in r07b.
+The self-check itself was measured (profiles/r07v_stream_settle.txt: never anything to replace) and removed: apply
+tools/patches/r07_stream_self_check.diff and `make variant NAME=meas` to run this again; without it the last column reads n/a."""
 import os
 import sys
 
@@ -24,7 +26,7 @@ def main():
     tr = bench.timed_run(leg, K, 100, lambda: (leg.hp.synchronize(), torch.cuda.synchronize()), 8, age_frames=300, export=False, spin=0.0)
     k1 = bench.k1_ms(tr["prof"])[0]
     print(f"{mode:9s} settle {os.environ.get('OATGPU_SETTLE_STREAMS', '1')} {wl:8s} fps {leg.ns * K / tr['block_s']:9.1f}  step {tr['block_s'] / K * 1e6:7.2f} us  "
-          f"K1 {k1 * 1e3:6.1f} us  streams replaced {leg.hp.lib.oatgpu_streams_replaced()}", flush=True)
+          f"K1 {k1 * 1e3:6.1f} us  streams replaced {getattr(leg.hp.lib, 'oatgpu_streams_replaced', lambda: 'n/a')()}", flush=True)
     leg.close()
 
 
