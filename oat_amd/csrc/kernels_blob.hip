@@ -179,8 +179,14 @@ constexpr int kRsWaves = 4, kRsRows = 4;
 
 #ifdef OATGPU_RS_TIMING             // measurement builds only (make variant DEFS=-DOATGPU_RS_TIMING, tools/rowscan_probe.py)
 constexpr unsigned kRsTkRing = 1u << 16;
-__device__ long long g_rs_tk[kRsTkRing * 4u];       // {first instruction, last instruction, row group, tag} of a row group (100 MHz wall clock)
+__device__ long long g_rs_tk[kRsTkRing * 5u];       // {first instruction, last instruction, row group, tag} of a row group (100 MHz wall clock)
 __device__ unsigned g_rs_tk_n;
+__device__ const unsigned long long *g_rs_k1_end;   // where the per-pixel launches stamp the end of their last workgroups
+void oatgpu_debug_rs_set_k1_end(const unsigned long long *p)
+{
+    static const unsigned long long *cur = nullptr;
+    if (p != cur) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rs_k1_end), &p, sizeof p); cur = p; }
+}
 extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(long long *out, int max_rows)
 {
     unsigned n = 0;
@@ -188,7 +194,7 @@ extern "C" __attribute__((visibility("default"))) int oatgpu_debug_rs_timing(lon
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rs_tk_n), sizeof n) != hipSuccess) return -1;
     const unsigned rows = n < kRsTkRing ? n : kRsTkRing;
     const unsigned take = rows < (unsigned)max_rows ? rows : (unsigned)max_rows;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_tk), (size_t)take * 4u * sizeof(long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_tk), (size_t)take * 5u * sizeof(long long)) != hipSuccess) return -1;
     return (int)take;
 }
 #endif
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
     {
 #ifdef OATGPU_RS_TIMING
     const long long rs_t0 = wall_clock64();
+    const long long rs_k1_end_seen = g_rs_k1_end ? (long long)__hip_atomic_load(g_rs_k1_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
 #endif
     constexpr int NT = 64 * WAVES;
     const int lane = threadIdx.x & 63;
@@ -345,7 +352,8 @@ __global__ __launch_bounds__(64 * kRsWaves) void k_rowscan(Geom g, const u64 *sr
 #ifdef OATGPU_RS_TIMING
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         const unsigned slot = atomicAdd(&g_rs_tk_n, 1u) & (kRsTkRing - 1u);
-        g_rs_tk[slot * 4u] = rs_t0; g_rs_tk[slot * 4u + 1] = wall_clock64(); g_rs_tk[slot * 4u + 2] = grp; g_rs_tk[slot * 4u + 3] = tag;
+        g_rs_tk[slot * 5u] = rs_t0; g_rs_tk[slot * 5u + 1] = wall_clock64(); g_rs_tk[slot * 5u + 2] = grp; g_rs_tk[slot * 5u + 3] = tag;
+        g_rs_tk[slot * 5u + 4] = rs_k1_end_seen;
     }
 #else
     (void)tag;

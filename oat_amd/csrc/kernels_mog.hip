@@ -928,6 +928,10 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
     if (thr_out && lane == 0) thr_out[(size_t)s * nwords + widx] = word;
     au.run(thr_out && lane == 0, 8, true);
     au.flush(a.audit, lane, valid);
+#ifdef OATGPU_RS_TIMING             // measurement builds (tools/rowscan_probe.py): when did the launch's LAST workgroups finish?  
+    if (!AUDIT && a.rs_end && lane == 0 && blockIdx.x + 512u >= gridDim.x)
+        __hip_atomic_fetch_max(a.rs_end, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #undef CUT
 #undef LDW
 #undef STW

@@ -192,6 +192,9 @@ struct oatgpu_ctx {
 
     // traffic audit (oatgpu_traffic_audit)
     unsigned long long *audit_dev = nullptr;   // 8 counters
+#ifdef OATGPU_RS_TIMING
+    unsigned long long *rs_k1_end = nullptr;   // (leaked at destroy: measurement builds only)
+#endif
     unsigned long long *wild_sink = nullptr;   // 8 counters nobody reads: launches outside div_inrange's operands (kernels_mog.hip)
     std::vector<char> wild_model;              // [n_streams] 1: an imported model with weights no run of the kernel produces
     bool audit_on = false;
@@ -812,6 +815,11 @@ static MogLaunch mog_launch_base(oatgpu_ctx *c, const uint8_t *frames, const Rat
     a.mp = mogparams_of(c->cfg);
     a.rp = range_of(c->cfg);
     a.audit = c->audit_on ? c->audit_dev : nullptr;
+#ifdef OATGPU_RS_TIMING             // measurement builds: the per-pixel launch's last workgroups stamp the wall clock here (kernels_mog.hip)
+    if (!c->rs_k1_end && hipMalloc((void **)&c->rs_k1_end, 64) == hipSuccess) hipMemset(c->rs_k1_end, 0, 64);
+    a.rs_end = c->rs_k1_end;
+    oatgpu::oatgpu_debug_rs_set_k1_end(c->rs_k1_end);
+#endif
     if (c->audit_on) c->audit_launches++;
     return a;
 }

@@ -100,6 +100,9 @@ struct MogLaunch {
                                  // audited launches: 1 when the PRODUCT launcher would have picked a frozen-model instantiation
                                  // for this launch (launch_mog_fused: every rate 0, default-policy loads, not fresh) -- the audit
                                  // then counts a fitted record's store only where its bits changed, as that kernel stores
+#ifdef OATGPU_RS_TIMING
+    unsigned long long *rs_end;  // measurement builds: the launch's last workgroups stamp the wall clock here (tools/rowscan_probe.py)
+#endif
 };
 
 // --- kernels_mog.hip ---
@@ -196,6 +199,9 @@ struct KalmanLaunch {
     int threshold;           // not_found_count_threshold_ = (int)(timeout / dt)
     unsigned ticket;         // this frame's index
 };
+#ifdef OATGPU_RS_TIMING
+void oatgpu_debug_rs_set_k1_end(const unsigned long long *p);     // measurement builds (kernels_blob.hip)
+#endif
 void launch_kalman(const KalmanLaunch &k, ResultRec *results, int n_streams, hipStream_t st);
 void launch_kalman_reset(KalmanState *state, int n_streams, unsigned ticket, hipStream_t st);
 

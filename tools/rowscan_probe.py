@@ -41,12 +41,12 @@ def main():
             leg.hp.track_dev(leg.pool[leg.pool_index(leg.step + i)].data_ptr())
     torch.cuda.synchronize()
     N = 1 << 16
-    buf = (C.c_longlong * (N * 4))()
+    buf = (C.c_longlong * (N * 5))()
     n = lib.oatgpu_debug_rs_timing(buf, N)
     launches = defaultdict(list)
     for r in range(n):
-        t0, t1, wg, tag = buf[r * 4], buf[r * 4 + 1], buf[r * 4 + 2], buf[r * 4 + 3]
-        launches[tag].append((t0, t1, wg))
+        t0, t1, wg, tag, k1e = buf[r * 5], buf[r * 5 + 1], buf[r * 5 + 2], buf[r * 5 + 3], buf[r * 5 + 4]
+        launches[tag].append((t0, t1, wg, k1e))
     nwg = (leg.wl["rows"] + 3) // 4
     # (early order: the two frames of a step carry the same ticket on their two scratch sets -- 2 x nwg entries a tag, run
     # side by side on two streams: split by first / second occurrence of a workgroup index in start order)
@@ -55,15 +55,17 @@ def main():
         if k == 0:
             continue
         v = sorted(v)
-        if len(v) == nwg:
-            full.append(v)
-        elif len(v) == 2 * nwg:
-            seen, one, two = set(), [], []
-            for w in v:
-                (two if w[2] in seen else one).append(w)
-                seen.add(w[2])
-            if len(one) == nwg and len(two) == nwg:
-                full += [one, two]
+        if len(v) % nwg:
+            continue
+        # (the scratch sets count their tickets separately: up to four launches -- sets 0..3 -- carry the same tag and run close
+        # together; the i-th occurrence of a row group in start order goes to the i-th of them)
+        parts, seen = [[] for _ in range(len(v) // nwg)], {}
+        for w in v:
+            i = seen.get(w[2], 0)
+            seen[w[2]] = i + 1
+            if i < len(parts):
+                parts[i].append(w)
+        full += [p_ for p_ in parts if len(p_) == nwg]
     if a.mode == "alone":      # untagged: cut the one list into launches of nwg workgroups by time
         allw = sorted(w for v in launches.values() for w in v)
         full = [allw[i:i + nwg] for i in range(0, len(allw) - nwg + 1, nwg)]
@@ -77,9 +79,18 @@ def main():
     run90 = [us(sorted(w[1] - w[0] for w in L)[int(len(L) * 0.9)]) for L in full]
     runmax = [us(max(w[1] - w[0] for w in L)) for L in full]
     m = st.median
+    # the per-pixel launch the row scan waited for ended at the latest stamp any of its workgroups saw that lies BEFORE the launch's first
+    # start (the next per-pixel launch stamps later ones while the row scan is still trickling in)
+    dep = []
+    for L in full:
+        first = L[0][0]
+        seen = [w[3] for w in L if 0 < w[3] <= first]
+        if seen:
+            dep.append(us(first - max(seen)))
     print(f"{a.workload} {a.mode}: {len(full)} launches x {nwg} workgroups; median over launches, us: first start -> last end {m(span):.1f}; "
           f"workgroup START after the first one's: p50 {m(start50):.1f}, p90 {m(start90):.1f}, last {m(startmax):.1f}; "
-          f"one workgroup RUNS: p50 {m(run50):.1f}, p90 {m(run90):.1f}, longest {m(runmax):.1f}")
+          f"one workgroup RUNS: p50 {m(run50):.1f}, p90 {m(run90):.1f}, longest {m(runmax):.1f}; "
+          + (f"first workgroup starts {m(dep):.1f} us (p90 {sorted(dep)[int(0.9 * len(dep))]:.1f}) behind the END of its per-pixel launch's last workgroups ({len(dep)} launches)" if dep else "no per-pixel end stamps"))
     leg.close()
 
 
