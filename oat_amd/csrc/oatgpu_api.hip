@@ -114,8 +114,9 @@ struct oatgpu_ctx {
     bool have_set[kSets] = {};       // scratch sets allocated: 0 .. nb-1 with the context, the others on first use
     int lone_plain = 1;              // a frame launched with NOTHING else outstanding (a camera-paced caller) takes the plain order even where the early
                                      // order is the default: no ticket kernel, no parked workgroup to release -- one frame at a time 133.5 -> 129.3 us at
-                                     // 4K, 89.6 -> 85.9 us for two 1080p streams, frame rate unchanged (profiles/r07t_lone_frame_plain_order_ab.txt;
-                                     // measurement builds: OATGPU_LONE_PLAIN=0)
+                                     // 4K, 89.6 -> 85.9 us for two 1080p streams, frame rate unchanged (profiles/r07t_lone_frame_plain_order_ab.txt) --
+                                     // and its back half goes to stream A itself (inline_back in launch_jobs: 4K 131 -> 122 us, one 1080p stream
+                                     // 66 -> 58.5 us, profiles/r07in_lone_frame_inline_ab.txt; measurement builds: OATGPU_LONE_PLAIN=0)
     int pair_back = 1;               // two-frame steps outside the early order: ONE row-scan launch and ONE blob launch for both frames
                                      // (measurement builds: OATGPU_PAIR_BACK=0)
     unsigned pair_steps = 0;         // paired steps so far (their parity picks the B stream and the two scratch sets)
@@ -1519,8 +1520,13 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
     c->last_step_early = early;
     // ONE "K1 done" event for the step: both frames' back halves wait for the same launch (a second record would be
     // a second marker packet between two K1s on stream A)
+    // A LONE frame (nothing else outstanding: a camera-paced caller) has its back half queued on stream A itself, right behind
+    // its per-pixel kernel: no event, no stream wait, and none of the ~10 us a dependency across two hardware queues takes
+    // (the gap between the two kernels in a trace of synchronous steps, profiles/r07_sync_step_timeline.txt).  Whatever is
+    // launched later waits for ITS per-pixel kernel, which queues behind this back half on A: the scratch set is safe.
+    const bool inline_back = lone && c->lone_plain && nj == 1 && !early && !c->use_graph && !c->serial && !(c->expt & 1);
     hipEvent_t k1_done = nullptr;
-    if (!(c->expt & 1)) {
+    if (!(c->expt & 1) && !inline_back) {
         const int nbe0 = (j[0].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
         k1_done = c->ev_k1[j[0].slot % nbe0];
     }
@@ -1686,8 +1692,8 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
         const int nbe = (j[i].ready && c->nb > 2 && !c->use_graph) ? 2 : c->nb;
         const int q = (share_b ? j[0].slot : slot) % nbe;
         const int k = slot;                              // threshold-bit buffer of this frame
-        hipStream_t B = c->serial ? c->stream : c->stream_b[q];
-        c->b_used[q] = true;
+        hipStream_t B = (c->serial || inline_back) ? c->stream : c->stream_b[q];
+        if (!inline_back) c->b_used[q] = true;
         ProfStep *pb = i == 0 ? ps : nullptr;           // the back half of the step's first frame is the sampled one
         if (c->expt & 1) {                               // K1 only: how fast can stream A go on its own?
             c->slot_ev[slot] = slot;
@@ -1695,7 +1701,7 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
             continue;
         }
         // Stream B[q]: morphology + blob analysis of this frame.
-        if (!(share_b && i == 1)) HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
+        if (!(share_b && i == 1) && !inline_back) HIPCHK(c, hipStreamWaitEvent(B, k1_done, 0));
         if (c->use_graph && !c->back_graph[slot]) {
             c->back_graph[slot] = capture_back_half(c, slot, B);
             if (!c->back_graph[slot]) c->use_graph = false;          // capture unsupported: plain launches
