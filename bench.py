@@ -118,6 +118,7 @@ def slim_line(full):
                                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     for k in ("value", "ms_per_step"):
         line[k] = _sig(line[k], 7)
+    line["value_mean"] = _sig(full.get("value_mean"), 7)
     line["config"] = {"workload": cfg.get("name"), "streams_per_gpu": cfg.get("streams_per_gpu"), "rows": cfg.get("rows"),
                       "cols": cfg.get("cols"), "erode": cfg.get("erode"), "dilate": cfg.get("dilate"),
                       "learning_rate": cfg.get("learning_rate"), "mog_mixtures": 5,
@@ -133,7 +134,10 @@ def slim_line(full):
         "measured_stream_copy_GBps": _sig(r.get("measured_stream_copy_GBps")),
         "leg": "4k1 dense (5 live modes a pixel)" if r.get("frac") is not None else None,
         "benched_launch_ms": _sig(_dig(r, "benched_workload", "avg_launch_ms")),
-        "benched_traffic": _sig(_dig(r, "benched_workload", "traffic"), 8)}
+        "benched_traffic": _sig(_dig(r, "benched_workload", "traffic"), 8),
+        "frac_benched_source": r.get("frac_benched_source"),
+        "k1_ms_ranks": ([_sig(_dig(r, "k_mog_fused_ms_ranks", "min"), 4), _sig(_dig(r, "k_mog_fused_ms_ranks", "max"), 4)]
+                        if r.get("k_mog_fused_ms_ranks") else None)}
     cb = full.get("cpu_baseline")
     if cb:
         host = cb.get("host") or {}
@@ -153,6 +157,7 @@ def slim_line(full):
     line["parity"] = full.get("parity")
     line["positions_found"] = full.get("positions_found")
     line["positions_expected"] = full.get("positions_expected")
+    line["positions_with_target"] = full.get("positions_with_target")
     ew = full.get("extra_workloads")
     line["extra_workloads"] = ({k: _sig(v.get("value"), 6) for k, v in ew.items()} if ew else None)
     line["extra_parity"] = ({k: v.get("parity") for k, v in ew.items() if v.get("parity") != "ok"} or "ok") if ew else None
@@ -173,9 +178,10 @@ def slim_line(full):
                                    for q in (pt.get("per_rank") or [])]}
     line["rccl"] = full.get("rccl")
     sc = full.get("scatter_ingest")
-    line["scatter_ingest"] = ({k: (_sig(v) if not isinstance(v, str) else v) for k, v in sc.items()
-                               if k in ("fps", "ms_per_step", "bytes_per_peer", "parity", "steps", "depth", "backend", "error")}
-                              if sc else None)
+    keep = ("fps", "ms_per_step", "bytes_per_peer", "parity", "steps", "depth", "backend", "error", "workload")
+    line["scatter_ingest"] = ({k: (_sig(v) if not isinstance(v, str) else v) for k, v in sc.items() if k in keep} if sc else None)
+    if sc and sc.get("also"):                      # N > 1: the other workload's shard through the same scatter
+        line["scatter_ingest"]["also"] = {k: (_sig(v) if not isinstance(v, str) else v) for k, v in sc["also"].items() if k in keep}
     line["device_open_retries"] = full.get("device_open_retries")
     line["timed_region_ms"] = _sig(full.get("timed_region_ms"))
     line["bench_wall_s"] = _sig(full.get("bench_wall_s"), 4)
@@ -786,6 +792,8 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
         if not timed_dev or not short[0] or attempts >= 3 or R >= R_max:
             break
         R = int(min(max(R + 1, R * 1.25 * min_ms / max(elapsed * 1e3, 1e-3) + 1), R_max))
+    first_step = leg.step - n            # the timed region's first step; pool frame 0 (it initialises the models) carries no disc
+    with_target = sum(1 for t in range(n) if leg.pool_index(first_step + t) != 0) * leg.ns
     if timed_dev:
         ends = [done[(b + 1) * K - 1] for b in range(R)]
         blocks = [ends[0]] + [ends[b] - ends[b - 1] for b in range(1, R)]
@@ -820,7 +828,7 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     return dict(block_s=median, local_block_s=local_block, blocks=blocks, n_blocks=R, region_s=region[0], steps_timed=n, isolated_block_s=iso,
                 positions=positions, found=found, prof=prof, models=models, handover=handover, aged=aged,
                 gate_offset=W + cal + skipped, step_s_calibration=t_cal, region_attempts=attempts,
-                saturated_latency_us=lat)
+                saturated_latency_us=lat, with_target=with_target)
 
 
 def single_frame_latency(leg, n):
@@ -895,6 +903,53 @@ def mode_histogram(leg):
     return dict(stream=0, modes_used=np.bincount(nm, minlength=6)[:6].tolist(),
                 live_modes=np.bincount(live, minlength=6)[:6].tolist(),
                 mean_modes_used=float(nm.mean()), mean_live_modes=float(live.mean()))
+
+
+# ------------------------------------------- N > 1: the other workload, every rank --
+
+def multi_rank_extra(name, K, W, local_rank, rank, world, reduce_max, args):
+    """N > 1: a SECOND gated leg on every rank -- BASELINE configs[3]'s shard (8 x 1080p a rank) beside configs[4]'s (one 4K
+    stream a rank), or the other way round -- so that ONE `bench.py --gpus N` run of the driver yields both of north_star's
+    sizes at N GPUs (N cameras with a chain each: examples/two-gige/two-gige.sh:7-8).  Same contract
+    as the main leg: barrier + device synchronisation on both sides, blocks of exactly K steps, max over ranks, both parity
+    gates on every rank for every stream of its shard.  Returns a dict on every rank; rank 0's holds the gathered ranks."""
+    import torch.distributed as dist
+    el = Leg(name, local_rank, rank, pool=24 if WORKLOADS[name]["streams"] >= 8 else args.pool)
+
+    def barrier():
+        el.hp.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+    try:
+        er = timed_run(el, K, max(W, 5), barrier, prof_every=8 if K >= 64 else 1, age_frames=AGE, export=not args.no_parity,
+                       spin=0.0, reduce_max=reduce_max)
+        par = "skipped"
+        if not args.no_parity:
+            par, _ = gates(el, er["gate_offset"], K, er["positions"], min(args.check_steps, 16), er["models"], er["handover"])
+        rec = dict(rank=rank, parity=par, found=er["found"], k_mog_fused_ms=k1_ms(er["prof"])[0],
+                   frames_per_launch=er["prof"]["mog_frames"] / max(er["prof"]["steps"], 1),
+                   ms_per_step_local=er["local_block_s"] / K * 1e3)
+    except Exception as e:               # never let the second leg take the first one's line down
+        log(f"[rank {rank}] extra workload {name} failed:", e)
+        er, rec = None, dict(rank=rank, parity=f"error: {str(e)[-160:]}", found=0, k_mog_fused_ms=None)
+    finally:
+        el.close()
+        torch.cuda.empty_cache()
+    allrec = [None] * world
+    dist.all_gather_object(allrec, rec)
+    if er is None or any(q.get("k_mog_fused_ms") is None for q in allrec):
+        return dict(name=name, value=None, parity=next(q["parity"] for q in allrec if q["parity"] != "ok"), per_rank=allrec)
+    w_ = WORKLOADS[name]
+    total = w_["streams"] * world
+    bad = [q for q in allrec if q["parity"] != "ok"]
+    k1s = [q["k_mog_fused_ms"] for q in allrec]
+    return dict(name=name, value=total * K / er["block_s"], unit="frames/s", steps=K, blocks=er["n_blocks"], warmup=max(W, 5),
+                streams_total=total, streams_per_gpu=w_["streams"], ms_per_step=er["block_s"] / K * 1e3,
+                timed_region_ms=er["region_s"] * 1e3, model_age_frames=er["handover"],
+                k_mog_fused_ms=max(k1s), k_mog_fused_ms_min=min(k1s), frames_per_launch=allrec[0]["frames_per_launch"],
+                px_per_launch=w_["rows"] * w_["cols"] * w_["streams"],
+                positions_found=sum(q["found"] for q in allrec), positions_expected=total * er["steps_timed"],
+                parity="ok" if not bad else f"rank {bad[0]['rank']}: {bad[0]['parity']}", per_rank=allrec)
 
 
 # -------------------------------------------------------- N > 1: scatter ingest --
@@ -986,7 +1041,7 @@ def scatter_leg(name, world, rank, dev, backend, steps, reduce_max, depth=2, gat
     return out
 
 
-def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_start):
+def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_start, also=None):
     """The scatter leg is the only part of an N > 1 run with a data-path exchange, and it runs LAST: should a transport hang
     (a peer that died, a P2P path that does not come up), a timer ends the rank instead of the job's default 10-minute
     collective timeout killing it without a line -- rank 0 first prints the line it already has, marked."""
@@ -1022,6 +1077,13 @@ def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_sta
     except Exception as e:
         log(f"[rank {rank}] scatter leg failed:", e)
         sc = dict(error=str(e)[-200:], parity="error", backend=args.backend)
+    if also:                             # the other workload's shard through the same scatter (fewer steps: it is the second leg)
+        try:
+            s2 = scatter_leg(also, world, rank, dev, args.backend, max(args.scatter_steps // 2, 12), reduce_max)
+        except Exception as e:
+            log(f"[rank {rank}] scatter leg ({also}) failed:", e)
+            s2 = dict(error=str(e)[-200:], parity="error", backend=args.backend)
+        sc["also"] = dict(s2, workload=also)
     done.set()
     t.cancel()
     if old_term is not None:
@@ -1447,11 +1509,17 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_rec)
 
+    # N > 1: the OTHER north-star size, every rank, gated (one invocation = the whole multi-GPU record)
+    extra_n = None
+    other = "1080p8" if args.workload != "1080p8" else "4k1"
+    if world > 1 and not args.no_extra and args.input == "device" and not args.dense_model:
+        extra_n = multi_rank_extra(other, K, W, local_rank, rank, world, reduce_max, args)
+
     if rank != 0:
         if world > 1:
             if want_scatter:
                 leg.close()
-                scatter_with_watchdog(args, world, rank, dev, reduce_max, None, t_start)
+                scatter_with_watchdog(args, world, rank, dev, reduce_max, None, t_start, other if extra_n else None)
             dist.barrier()              # rank 0 prints before everybody leaves
             dist.destroy_process_group()
         return
@@ -1726,6 +1794,21 @@ def main():
             benched["waste_ratio"] = benched["moved_bytes_per_px"] / max(benched["useful_bytes_per_px_launch_lower_bound"], 1e-9)
     roofline["frac_real"] = benched.get("frac_real")
     roofline["frac_benched"] = benched.get("frac_real")      # the workload `value` is measured on: PMC bytes / kernel time / peak
+    roofline["frac_benched_source"] = "pmc" if benched.get("frac_real") is not None else None
+    if world > 1 and per_rank:
+        # N > 1 (no profiler child passes): the SLOWEST rank's per-pixel launch, by HIP events on its own stream, priced at the
+        # bytes the kernel itself counted on rank 0's model (32-byte sectors its loads and stores touch; the ranks run the same
+        # synthetic input on models of the same age) -- the fraction a SCALE line carries
+        k1s = [q["k_mog_fused_ms"] for q in per_rank if q.get("k_mog_fused_ms")]
+        if k1s:
+            benched.update(avg_launch_ms=max(k1s), avg_launch_ms_min_rank=min(k1s), avg_launch_ms_rank0=mog_ms)
+            roofline["k_mog_fused_ms_ranks"] = {"min": min(k1s), "max": max(k1s)}
+            req = benched.get("requested_sector32_bytes_per_px")
+            if req and aud and abs(aud["frames_per_launch"] - fpl) < 1e-6:
+                b = req * px_per_launch
+                benched.update(traffic=b, traffic_source="kernel audit (32-byte sectors), rank 0")
+                roofline["frac_benched"] = b / (max(k1s) * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                roofline["frac_benched_source"] = "audit"
     naive = BYTES_PER_PIXEL * rows * cols * ns / (block_s / K) / 1e9      # SURVEY 8d's per-frame figure x the benched frame rate
     roofline["algorithmic_205B_x_fps_GBps"] = naive
     roofline["fractions"] = (
@@ -1747,6 +1830,8 @@ def main():
     line = {
         "metric": "frames/sec/GPU (1080p & 4K) mog+hsv+ccl fused; % HBM roofline",
         "value": fps,
+        # the whole timed region / its steps (every block, the first one's pipeline fill included): `value` is the MEDIAN block's
+        "value_mean": total_streams * tr["steps_timed"] / tr["region_s"],
         "value_one_frame_a_launch": one_frame["value"] if one_frame else None,
         "value_default_learning_rate_0": frozen["value"] if frozen else None,
         "unit": "frames/s",
@@ -1810,6 +1895,8 @@ def main():
         "scatter_ingest": None,
         "positions_found": n_found,
         "positions_expected": total_streams * tr["steps_timed"],
+        # ... of which frames that carry a target: pool frame 0 (it initialises the models) has no disc and recurs once a pool cycle
+        "positions_with_target": world * tr["with_target"],
         "parity": parity,
         "parity_detail": parity_detail,
         "input": args.input,
@@ -1820,6 +1907,8 @@ def main():
         line["extra_workloads"] = extra
         line["one_frame_a_launch"] = one_frame
         line["default_learning_rate_0"] = frozen
+    if extra_n:                                    # N > 1: the other north-star size, all ranks, gated
+        line["extra_workloads"] = {extra_n["name"]: extra_n}
 
     line["pipeline"] = None
     if solo and not args.no_pipeline and args.input == "device" and not args.dense_model:
@@ -1834,7 +1923,7 @@ def main():
     else:
         line["cpu_baseline"] = None
     if want_scatter:                               # last: nothing the line needs from the other ranks is still outstanding
-        line["scatter_ingest"] = scatter_with_watchdog(args, world, rank, dev, reduce_max, line, t_start)
+        line["scatter_ingest"] = scatter_with_watchdog(args, world, rank, dev, reduce_max, line, t_start, other if extra_n else None)
         sc = line["scatter_ingest"] or {}
         log(f"scatter_ingest: {sc.get('fps')} fps, {sc.get('ms_per_step')} ms/step, {sc.get('bytes_per_peer')} B/peer/step, parity {sc.get('parity')}")
     line["bench_wall_s"] = time.perf_counter() - t_start

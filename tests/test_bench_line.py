@@ -29,14 +29,24 @@ def _eight_ranks(full):
     d = copy.deepcopy(full)
     d["n_gpus"] = 8
     d["cpu_baseline"] = None
-    d["extra_workloads"] = d["pipeline"] = None
-    d["roofline"] = {"bound": "hbm", "kernel": "k_mog_fused", "peak": 8000.0, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None}
+    d["pipeline"] = None
+    # N > 1 (r08): the other north-star size on every rank, and the benched launch priced from the slowest rank's HIP events
+    d["extra_workloads"] = {"1080p8": dict(name="1080p8", value=612345.678, unit="frames/s", steps=20, blocks=9, parity="ok",
+                                           k_mog_fused_ms=0.2212345, k_mog_fused_ms_min=0.2112345, streams_total=64,
+                                           per_rank=[dict(rank=r, parity="ok", found=1000, k_mog_fused_ms=0.22) for r in range(8)])}
+    d["roofline"] = {"bound": "hbm", "kernel": "k_mog_fused", "peak": 8000.0, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+                     "frac_benched": 0.61234567, "frac_benched_source": "audit", "k_mog_fused_ms_ranks": {"min": 0.0991234, "max": 0.1012345},
+                     "benched_workload": {"avg_launch_ms": 0.1012345, "traffic": 496123456.0}}
+    d["value_mean"] = d["value"] * 0.99
+    d["positions_with_target"] = 11600
     d["partition"] = {"rule": "x" * 150, "streams_total": 64,
                       "per_rank": [dict(rank=r, device=r, streams=[8 * r, 8 * r + 8], parity="ok", positions_found=12345,
                                         block_ms=10.123456789, k_mog_fused_ms=0.20123456, ms_per_step_local=0.1012345) for r in range(8)]}
     d["rccl"] = {"ranks": 8, "backend": "nccl", "version": "2.26.6"}
     d["scatter_ingest"] = dict(fps=123456.789, ms_per_step=0.51234567, steps=192, depth=2, backend="nccl", bytes_per_peer=49766400,
-                               parity="ok", per_rank=[dict(rank=r, parity="ok", found=100) for r in range(8)], what="y" * 400)
+                               parity="ok", per_rank=[dict(rank=r, parity="ok", found=100) for r in range(8)], what="y" * 400,
+                               also=dict(workload="1080p8", fps=423456.789, ms_per_step=0.15123456, steps=96, depth=2, backend="nccl",
+                                         bytes_per_peer=49766400, parity="ok", per_rank=[dict(rank=r, parity="ok") for r in range(8)], what="y" * 400))
     d["latency_us"] = dict(saturated_p50=415.123456, saturated_p99=460.1, ring_depth=8, single_p50=180.2, single_p99=199.9)
     return d
 
@@ -71,6 +81,14 @@ def test_slim_line_is_small_parseable_and_complete(shape):
         assert j["scatter_ingest"]["parity"] == "ok" and j["scatter_ingest"]["bytes_per_peer"] == 49766400
         assert "what" not in j["scatter_ingest"] and "per_rank" not in j["scatter_ingest"]
         assert j["rccl"]["ranks"] == 8
+        # the whole N > 1 record in the one line
+        assert j["extra_workloads"] == {"1080p8": pytest.approx(612345.678, rel=1e-5)} and j["extra_parity"] == "ok"
+        assert j["roofline"]["frac_benched"] == pytest.approx(0.6123, rel=1e-3) and j["roofline"]["frac_benched_source"] == "audit"
+        assert j["roofline"]["k1_ms_ranks"] == [pytest.approx(0.09912, rel=1e-3), pytest.approx(0.1012, rel=1e-3)]
+        assert j["roofline"]["benched_launch_ms"] == pytest.approx(0.10123, rel=1e-3)
+        also = j["scatter_ingest"]["also"]
+        assert also["workload"] == "1080p8" and also["parity"] == "ok" and "what" not in also and "per_rank" not in also
+        assert j["value_mean"] == pytest.approx(full["value"] * 0.99, rel=1e-5) and j["positions_with_target"] == 11600
     # no prose: nothing in the line is a long string
     def longest(o):
         if isinstance(o, str):

@@ -99,7 +99,7 @@ def test_bench_eight_ranks_on_one_gpu_run_configs_3_and_4(workload, per_rank):
     cmd = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
                         "--workload", workload, "--steps", str(K), "--warmup", "5", "--age", "40", "--pool", "8", "--check-steps", "4",
-                        "--no-spin-up", "--scatter-steps", "12"]
+                        "--no-spin-up", "--scatter-steps", "12", "--no-extra"]
     r = _launch(cmd, env, 900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -121,6 +121,45 @@ def test_bench_eight_ranks_on_one_gpu_run_configs_3_and_4(workload, per_rank):
     assert abs(j["value"] - 8 * per_rank * K / (j["ms_per_step"] * K / 1e3)) < 1e-5 * j["value"]
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] is None and j.get("extra_workloads") is None
     assert j["scatter_ingest"]["parity"] == "ok" and j["scatter_ingest"]["bytes_per_peer"] == per_rank * (1080 * 1920 if per_rank == 8 else 2160 * 3840) * 3
+
+
+def test_the_drivers_own_multi_gpu_command_yields_the_whole_record_on_one_gpu():
+    """`python3 bench.py --gpus 8 --steps 20 --warmup 5` -- the driver's exact argv for its one-shot SCALE run, plus `--backend
+    gloo` so that eight ranks can share the one GPU there is here.  ONE invocation, no launcher in front,
+    default ageing / pool / gates: one line <= 4 KB with n_gpus 8 that carries BOTH north-star sizes at N GPUs -- `value` on
+    configs[4]'s shard (one 4K stream a rank) and `extra_workloads.1080p8` on configs[3]'s (8 x 1080p a rank), both parity
+    gates green on every rank for both --, the benched per-pixel launch as a fraction of the HBM peak from the slowest
+    rank's HIP events (no profiler child at N > 1), the per-rank kernel times, and the stream->rank scatter for both sizes."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = lambda port: [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--backend", "gloo"]
+    t0 = time.perf_counter()
+    r = _launch(cmd, env, 900)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert wall < 900
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 20 and j["warmup"] == 5 and j["config"]["workload"] == "4k1"
+    assert j["parity"] == "ok" and [q[4] for q in j["partition"]["ranks"]] == ["ok"] * 8
+    assert set(j["extra_workloads"]) == {"1080p8"} and j["extra_workloads"]["1080p8"] > 0 and j["extra_parity"] == "ok"
+    d = _detail()
+    ex = d["extra_workloads"]["1080p8"]
+    assert ex["streams_total"] == 64 and [q["parity"] for q in ex["per_rank"]] == ["ok"] * 8 and ex["timed_region_ms"] >= 50.0
+    assert ex["value"] == pytest.approx(64 * 20 / (ex["ms_per_step"] * 20 / 1e3), rel=1e-6)
+    rf = j["roofline"]
+    assert rf["frac"] is None and rf["frac_benched"] is not None and 0.0 < rf["frac_benched"] < 1.0 and rf["frac_benched_source"] == "audit"
+    assert rf["benched_launch_ms"] == pytest.approx(rf["k1_ms_ranks"][1], rel=1e-3) and rf["k1_ms_ranks"][0] <= rf["k1_ms_ranks"][1]
+    assert all(q[5] and q[5] > 0 for q in j["partition"]["ranks"])                 # every rank's k_mog_fused ms
+    sc = j["scatter_ingest"]
+    assert sc["parity"] == "ok" and sc["bytes_per_peer"] == 2160 * 3840 * 3
+    assert sc["also"]["workload"] == "1080p8" and sc["also"]["parity"] == "ok" and sc["also"]["bytes_per_peer"] == 8 * 1080 * 1920 * 3
+    assert j["rccl"] == {"ranks": 8, "backend": "gloo", "version": None}
+    assert j["value_mean"] > 0 and j["positions_with_target"] <= j["positions_expected"]
+    with open(os.path.join(ROOT, "gpurun_out", "drivers_multi_gpu_command_wall_s.txt"), "w") as f:
+        f.write("%.1f s wall, line %d bytes\n%s\n" % (wall, len(lines[0]), lines[0]))
 
 
 def test_rccl_single_rank_init_allreduce_teardown():
