@@ -79,8 +79,11 @@ AGE = 600                       # frames a model has seen before anything is war
 MIN_TIMED_MS = 50.0             # below this a timed region says little: flagged in the line
 
 
+_T_PROCESS = time.perf_counter()
+
+
 def log(*a):
-    print(*a, file=sys.stderr, flush=True)
+    print(f"[+{time.perf_counter() - _T_PROCESS:6.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OATGPU_ABI_VERSION 8     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, oatgpu_set_deferred / _fetch_frame / _fetch_position, a failed pipelined launch is fatal for its context; 8: oatgpu_track_sequence_dev_latency, oatgpu_device_open_retries, oatgpu_set_k1_workgroup, oatgpu_last_step_shape, oatgpu_early_blob_timeouts, a parked blob workgroup that times out switches early dispatch off for its context */
+#define OATGPU_ABI_VERSION 9     /* 2: oatgpu_position grew (filter outputs), new entry points; 3: oatgpu_config.mog_restore_nmodes; 4: oatgpu_cvt_color, oatgpu_set_fusion, oatgpu_set_homography, oatgpu_profile.mog_frames; 5: oatgpu_track_sequence_dev_timed, oatgpu_track_enqueue_dev pairs frames only after oatgpu_set_fusion(2); 6: oatgpu_track_input_consumed_stream, oatgpu_track_stage, oatgpu_track_enqueue_staged; 7: oatgpu_track_stage_abort, oatgpu_set_early_blob, oatgpu_set_stage_copy, oatgpu_set_deferred / _fetch_frame / _fetch_position, a failed pipelined launch is fatal for its context; 8: oatgpu_track_sequence_dev_latency, oatgpu_device_open_retries, oatgpu_set_k1_workgroup, oatgpu_last_step_shape, oatgpu_early_blob_timeouts, a parked blob workgroup that times out switches early dispatch off for its context; 9: oatgpu_profile.dropped, every scratch set is allocated by oatgpu_create (an out-of-memory is reported there, never in the middle of a step) */
 
 enum {
     OATGPU_OK = 0,
@@ -131,6 +131,9 @@ typedef struct oatgpu_profile {
                                   besides kernel execution); measured at profile_enable */
     int64_t mog_frames;        /* frames the `steps` measured launches of the fused kernel covered
                                   (steps .. 2 * steps, see oatgpu_set_fusion)              */
+    int64_t dropped;           /* samples left out: their per-pixel launch read more than 8 x the running average -- a host
+                                  thread descheduled between the event record and the launch call puts its absence into the
+                                  pair; at most 4 in a row (a 5th is a change of regime and is taken)  */
 } oatgpu_profile;
 
 typedef struct oatgpu_ctx oatgpu_ctx;
@@ -196,12 +199,14 @@ int oatgpu_set_fusion(oatgpu_ctx *ctx, int32_t frames_per_launch);
  * let the waiting workgroup run before the row scan it waits for; the kernel then gives up after 100 ms and the frame is
  * redone by the global kernels: correct, but slow. */
 int oatgpu_set_early_blob(oatgpu_ctx *ctx, int32_t on);
-/* Frames whose parked blob workgroup gave up after 100 ms because its row scan was not dispatched beside it (a tool that
- * serialises kernel dispatches).  The first one switches early dispatch off for the context (oatgpu_last_error says so);
- * the frames themselves were redone by the global kernels: results are unaffected. */
+/* 1 once a parked blob workgroup of this context has given up after 100 ms because its row scan was not dispatched beside it
+ * (a tool that serialises kernel dispatches), else 0.  It switches early dispatch off for the context (oatgpu_last_error
+ * says so) and raises a flag on the device at which the workgroups parked behind it decline without waiting; all those
+ * frames are redone by the global kernels: results are unaffected, and the episode costs its caller 100 ms once. */
 int64_t oatgpu_early_blob_timeouts(const oatgpu_ctx *ctx);
 /* Threads of a workgroup of the fused per-pixel kernel on the pipelined path: 0 (default) by path -- 64 (one wave a
- * workgroup) where the step's blob workgroup is dispatched early or the model is dense, 256 otherwise -- or 64 / 256
+ * workgroup) where the step's blob workgroup is dispatched early, where a LONE frame (nothing else outstanding) of a
+ * context that would use the early order is launched, or the model is dense; 256 otherwise -- or 64 / 256
  * whatever the path.  Results are identical.  For profiling the shipped instantiation under a tool that needs
  * oatgpu_set_early_blob(0) (bench.py's counter passes). */
 int oatgpu_set_k1_workgroup(oatgpu_ctx *ctx, int32_t threads);

@@ -451,4 +451,4 @@ class HotPath(_Context):
         p = ffi.Profile()
         self._chk(self.lib.oatgpu_profile_read(self.ctx, C.byref(p)))
         return dict(steps=p.steps, mog_ms=p.mog_ms, morph_ms=p.morph_ms, blob_ms=p.blob_ms, total_ms=p.total_ms,
-                    event_pair_ms=p.event_pair_ms, mog_frames=p.mog_frames)
+                    event_pair_ms=p.event_pair_ms, mog_frames=p.mog_frames, dropped=p.dropped)

@@ -810,8 +810,15 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
             int bad = 0;
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(&b.ready[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_ticket) {
+                // (somebody serialises kernel dispatches and a workgroup of this context has already waited its 100 ms in vain:
+                // the host learns of it only when it collects that frame -- the frames parked behind it must not pay again)
+                if (__hip_atomic_load(b.nopark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = kPathNoPark; break; }
                 __builtin_amdgcn_s_sleep(16);
-                if (wall_clock64() - t0 > kWaitTicks) { bad = 1; break; }
+                if (wall_clock64() - t0 > kWaitTicks) {
+                    bad = kPathTimeout;
+                    __hip_atomic_store(b.nopark, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
             wait_failed = bad;
         }
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_blob_lds(Geom g, BlobBuffers b0, 
         if (wait_failed) {
             if (t == 0) {
                 b.lds_ok[s] = 0u;
-                if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; r.path = kPathTimeout; results[s] = r; }
+                if (spec) { ResultRec r{}; r.first_pixel = -1; r.valid = kNeedsGlobal; r.path = wait_failed; results[s] = r; }
             }
             return;
         }

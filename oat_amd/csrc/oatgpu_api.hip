@@ -105,13 +105,14 @@ struct oatgpu_ctx {
                                      // 0 / 1 forced (measurement builds: OATGPU_K1_STOP_EVENT)
     size_t early_min_px = 4000000;   // pixels a step from which the early order is considered (measurement builds: OATGPU_EARLY_MIN_PX)
     int k1_wg_force = 0;             // oatgpu_set_k1_workgroup (64 | 256): the per-pixel kernel's workgroup size whatever the path
+    unsigned *nopark = nullptr;      // device word: a parked blob workgroup of this context has timed out (BlobBuffers::nopark)
     unsigned long long early_timeouts = 0;   // frames whose parked blob workgroup gave up waiting for its row scan (kWaitTicks):
                                      // something serialises kernel dispatches -- the context then stops parking (early_off)
     bool early_off = false;
     int last_k1_wg = 0;              // what the latest pipelined step used (oatgpu_last_step_shape)
     bool last_step_early = false;
     int last_early = -1;             // path of the previous step (-1: none yet; 0 plain, 1 early, 2 paired): a switch drains the B streams first
-    bool have_set[kSets] = {};       // scratch sets allocated: 0 .. nb-1 with the context, the others on first use
+    bool have_set[kSets] = {};       // scratch sets allocated (all of them in oatgpu_create when nb >= 3)
     int lone_plain = 1;              // a frame launched with NOTHING else outstanding (a camera-paced caller) takes the plain order even where the early
                                      // order is the default: no ticket kernel, no parked workgroup to release -- one frame at a time 133.5 -> 129.3 us at
                                      // 4K, 89.6 -> 85.9 us for two 1080p streams, frame rate unchanged (profiles/r07t_lone_frame_plain_order_ab.txt) --
@@ -171,7 +172,7 @@ struct oatgpu_ctx {
     uint8_t *diff_last = nullptr;  // [n][H*W] previous GREY frame of posidet diff, allocated on first use
     std::vector<char> diff_have;   // per camera stream
     u64 *roi = nullptr;            // [n][Palloc/64] ROI bits, allocated on first oatgpu_set_roi_mask
-    BlobBuffers bb[kSets]{};          // scratch sets (bb[0].thr holds the ring's threshold buffers): nb made with the context, the rest on first use
+    BlobBuffers bb[kSets]{};          // scratch sets (bb[0].thr holds the ring's threshold buffers), all made with the context
     const u64 *last_morph = nullptr;
     const u64 *last_fin = nullptr;
     ResultRec *res_host = nullptr; // [ring_depth+1][n] pinned + mapped (last slot: single-stage calls)
@@ -189,6 +190,7 @@ struct oatgpu_ctx {
     std::vector<ProfStep> prof_steps;
     size_t prof_used = 0;
     oatgpu_profile prof_sum{};
+    int prof_drop_streak = 0;      // consecutive samples prof_fold took for host stalls
     double event_pair_ms = 0.0;
 
     // traffic audit (oatgpu_traffic_audit)
@@ -394,6 +396,7 @@ static void free_all(oatgpu_ctx *c)
     if (!c) return;
     hipFree(c->bsub_bg); hipFree(c->bsub_f); hipFree(c->diff_last); hipFree(c->roi); hipFree(c->state); hipFree(c->nmodes); hipFree(c->frames); hipFree(c->aux_a); hipFree(c->aux_b);
     hipFree(c->bb[0].thr);
+    hipFree(c->nopark);
     hipFree(c->kal.state);
     hipFree(c->audit_dev);
     hipFree(c->wild_sink);
@@ -447,6 +450,10 @@ static hipError_t open_device(int device, int *ndev)
             e = hipErrorNoDevice;
         }
         (void)hipGetLastError();
+        // (a box WITHOUT a device says so at the first call -- hipErrorNoDevice, or a count of 0 -- and is not kept
+        // waiting 1.5 s for one on every oatgpu_create; what the retry absorbs is a device that exists and is busy being
+        // initialised by a sibling process: any other error, or "no device" after a first attempt that saw one)
+        if (attempt == 0 && e == hipErrorNoDevice) break;
         if (attempt == 5) break;
         g_open_retries++;
         usleep(50000u << attempt);
@@ -455,8 +462,11 @@ static hipError_t open_device(int device, int *ndev)
 }
 extern "C" int oatgpu_device_open_retries(void) { return g_open_retries.load(); }
 
-// One scratch set of the back half (BlobBuffers; about 30 bytes a pixel and stream), its counters zeroed.  Sets 0 .. nb-1 are
-// made with the context; the paired back half (launch_jobs) adds a fourth on first use.
+// One scratch set of the back half (BlobBuffers; about 30 bytes a pixel and stream), its counters zeroed.  ALL sets a context
+// can come to use are made with it (oatgpu_create): the three of the plain order, the fourth of the early and
+// the paired layout, and the repair set -- 150 bytes a pixel and stream in all.  An allocation in the middle of a pipelined
+// step would stall a camera-paced caller for as long as hipMalloc takes, and its failure would come after the model had
+// moved.  launch_jobs keeps the on-first-use path only for measurement builds that shrink nb.
 static bool alloc_scratch_set(oatgpu_ctx *c, int q)
 {
     const Geom &g = c->g;
@@ -465,6 +475,7 @@ static bool alloc_scratch_set(oatgpu_ctx *c, int q)
     bool ok = true;
     auto A = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
     b.thr = c->bb[0].thr;
+    b.nopark = c->nopark;
     A((void **)&b.tmp, n * NW * 8);
     A((void **)&b.morph, n * NW * 8);
     A((void **)&b.fin, n * NW * 8);
@@ -580,8 +591,11 @@ extern "C" oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg)
     // One threshold-bit buffer per ring slot: a slot is only reused after its result was collected,
     // i.e. after the back half that read its buffer has finished -- stream A never waits for a B stream.
     A((void **)&c->bb[0].thr, (size_t)c->ring_slots * n * NW * 8);
-    for (int q = 0; q < c->nb && ok; ++q) ok = alloc_scratch_set(c, q);
-    for (int q = 0; q < c->nb && ok; ++q) c->have_set[q] = true;
+    A((void **)&c->nopark, sizeof(unsigned));
+    if (ok && hipMemsetAsync(c->nopark, 0, sizeof(unsigned), c->stream) != hipSuccess) ok = false;
+    const int nsets = c->nb >= 3 ? oatgpu_ctx::kSets : c->nb;      // (an out-of-memory shows HERE, as OATGPU_E_NOMEM from oatgpu_create)
+    for (int q = 0; q < nsets && ok; ++q) ok = alloc_scratch_set(c, q);
+    for (int q = 0; q < nsets && ok; ++q) c->have_set[q] = true;
     const size_t slots = (size_t)c->ring_slots + 1;
     if (ok && hipHostMalloc((void **)&c->res_host, slots * n * sizeof(ResultRec), hipHostMallocMapped) != hipSuccess)
         ok = false;
@@ -1284,7 +1298,15 @@ static void prof_fold(oatgpu_ctx *c)
         // (a host thread descheduled between the first event's record and the launch call puts its absence INTO the event
         // pair: one 10 ms sample among 145 turned a 100 us average into 238 us, profiles/r07z run of the driver's arguments.  A
         // sample eight times the average of those taken so far is the host's, not the kernel's: dropped.)
-        if (c->prof_sum.steps >= 8 && a > 8.0 * (c->prof_sum.mog_ms / (double)c->prof_sum.steps)) continue;
+        // (the drops are COUNTED -- oatgpu_profile.dropped -- and bounded: four in a row are no host hiccup but a
+        // change of regime, e.g. one-frame steps on a sparse model followed by two-frame steps on a dense one; the sample is
+        // then taken and the streak starts anew, so the profile cannot freeze on its first eight samples.)
+        if (c->prof_sum.steps >= 8 && a > 8.0 * (c->prof_sum.mog_ms / (double)c->prof_sum.steps) && c->prof_drop_streak < 4) {
+            c->prof_sum.dropped += 1;
+            c->prof_drop_streak++;
+            continue;
+        }
+        c->prof_drop_streak = 0;
         c->prof_sum.steps += 1;
         c->prof_sum.mog_frames += p.frames;
         c->prof_sum.mog_ms += a; c->prof_sum.morph_ms += b; c->prof_sum.blob_ms += d; c->prof_sum.total_ms += t;
@@ -1394,6 +1416,8 @@ extern "C" int oatgpu_track_enqueue_staged(oatgpu_ctx *c, double lr)
     if (!c) return OATGPU_E_INVALID;
     const int n = c->cfg.n_streams;
     if (c->staged_count != n) return fail(c, OATGPU_E_INVALID, "%d of %d streams staged", c->staged_count, n);
+    if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first (oatgpu_fetch_frame / oatgpu_fetch_position)");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int slot = c->stage_slot;
     const size_t sb = (size_t)c->g.H * c->g.W * c->cfg.channels * n;
@@ -1435,6 +1459,10 @@ extern "C" int oatgpu_track_enqueue(oatgpu_ctx *c, const uint8_t *const *frames_
 {
     if (!c || !frames_host) return fail(c, OATGPU_E_INVALID, "null argument");
     if (n != c->cfg.n_streams) return fail(c, OATGPU_E_INVALID, "expected %d frames, got %d", c->cfg.n_streams, n);
+    // (refused BEFORE a copy out of the caller's frames is queued -- enqueue_frames checks the same again, but by
+    // then stream C would be reading buffers of a call that fails, and input_consumed would wait on a set nobody registered)
+    if (c->broken) return fail(c, OATGPU_E_HIP, "context unusable after a failed launch (destroy it): %s", c->err.c_str());
+    if (c->defer_kind) return fail(c, OATGPU_E_INVALID, "a deferred result is waiting: fetch it first (oatgpu_fetch_frame / oatgpu_fetch_position)");
     if (c->ring_count == c->cfg.ring_depth) return fail(c, OATGPU_E_RING_FULL, "result ring full: collect first");
     for (int s = 0; s < n; ++s) if (!frames_host[s]) return fail(c, OATGPU_E_INVALID, "null frame %d", s);
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1583,7 +1611,9 @@ static int launch_jobs(oatgpu_ctx *c, const oatgpu_ctx::FrameJob *j, int nj, boo
     if (c->last_early >= 0 && c->last_early != path)          // the paths use the scratch sets from different streams
         for (int q = 0; q < oatgpu_ctx::kNB; ++q) if (c->stream_b[q] && c->b_used[q]) HIPCHK(c, hipStreamSynchronize(c->stream_b[q]));
     c->last_early = path;
-    // Scratch sets beyond the context's nb, on first use: 3 for the early and the paired layout; 4 = THE REPAIR SET -- every frame that
+    // Scratch sets 3 and 4 (made with the context; the loop below allocates only in measurement builds that shrank nb -- and then
+    // BEFORE anything of the step is recorded as launched would be too late anyway: those builds accept the stall): 3 for the
+    // early and the paired layout; 4 = THE REPAIR SET -- every frame that
     // goes through the LDS kernel alone (kBlobSpec), on whichever path, is repaired in set 4 on B2 if it is declined: each layout
     // ties its sets to streams in its own way (plain: set q on stream q; paired: sets 2p, 2p + 1 on stream p; early: sets 0..3 on
     // B0 / B1 by parity), a switch of layouts drains the streams, but a repair comes LATER -- at the frame's collect -- and must
@@ -1827,8 +1857,11 @@ static int launch_repair(oatgpu_ctx *c, int slot)
         // The blob workgroup was resident and its row scan never ran beside it: a tool serialises kernel dispatches (a
         // counter-collecting profiler, a debug layer) or too many contexts share the hardware queues.  Correct either way
         // (the global kernels redo the frame), but every such step costs 100 ms: stop parking for this context and say so.
-        c->early_timeouts++;
+        // (counted once: the frames that were parked in the same instant -- the second frame of a two-frame step, the steps a deep
+        // ring had launched before this one was collected -- belong to the same episode; they saw the device flag the first one
+        // set (BlobBuffers::nopark) and declined without waiting, or gave up in the very same 100 ms)
         if (!c->early_off) {
+            c->early_timeouts++;
             c->early_off = true;
             g_last_error = c->err = "early blob dispatch switched off for this context: a parked blob workgroup waited 100 ms for a row "
                                     "scan that was not dispatched beside it (kernel dispatches are being serialised); results are unaffected";
@@ -2347,5 +2380,6 @@ extern "C" int oatgpu_profile_reset(oatgpu_ctx *c)
     { const int frc = flush_pending(c); if (frc) return frc; }
     prof_fold(c);
     c->prof_sum = oatgpu_profile{};
+    c->prof_drop_streak = 0;
     return OATGPU_OK;
 }

@@ -173,6 +173,9 @@ struct BlobBuffers {
     // the early blob workgroup (kernels_blob.hip "Early dispatch"): a one-lane kernel behind the row scan publishes the frame's
     // ticket, the k_blob_lds workgroup that was dispatched ahead of it waits for exactly that ticket
     unsigned *ready;       // [n]          ticket of the latest frame whose row scan is complete (k_publish_ticket)
+    unsigned *nopark;      // [1], one per CONTEXT (every scratch set points at it): set by the first parked workgroup that gave up
+                           //              waiting -- the parked workgroups already in flight behind it decline at once instead of
+                           //              waiting their own 100 ms each (kPathNoPark)
 };
 struct ResultRec {   // device-side result, one per stream per step
     long long a00, a10, a01;
@@ -221,6 +224,7 @@ size_t rowscan_lds_bytes(const Geom &g, int dil_k);
 enum { kBlobFull = 0, kBlobSpec = 1, kBlobGlobal = 2 };
 constexpr int kNeedsGlobal = -2;
 constexpr int kPathTimeout = 2;
+constexpr int kPathNoPark = 3;     // beside valid == kNeedsGlobal: declined without waiting, an earlier workgroup of the context had timed out
 void launch_blob(const Geom &g, const BlobBuffers &b, const u64 *src_bits, int ero_k, int dil_k, double min_area,
                  double max_area, ResultRec *results, int first_stream, int n_streams, hipStream_t st, int mode = kBlobFull);
 // The same in two halves on two HIP streams (kernels_blob.hip "Early dispatch"): the row scan with a one-lane kernel behind

@@ -110,6 +110,7 @@ class FrameScatterPipe:
         self.xbuf = None
         if self.via_host and self.rank != src:
             self.xbuf = [torch.empty((self.per,) + self.shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.up_ev = [None] * depth         # via_host: the upload out of xbuf[k] has finished (post() must not receive into it before)
         self.work = [None] * depth          # outstanding requests of the slot
         self.keep = [None] * depth          # root: the frame tensor being sent out of
         self.step_of = [None] * depth
@@ -136,6 +137,9 @@ class FrameScatterPipe:
                 else:
                     ops.append(dist.P2POp(dist.isend, out[blk.start:blk.stop].contiguous(), peer, self.group))
         elif len(self.mine):
+            if self.via_host and self.up_ev[k] is not None:
+                self.up_ev[k].synchronize()         # (the receive below writes xbuf[k] from a CPU thread -- the
+                self.up_ev[k] = None                #  asynchronous upload that read it for step t - depth must be through)
             dst = self.xbuf[k] if self.via_host else self.buf[k]
             ops.append(dist.P2POp(dist.irecv, dst[:len(self.mine)], self.src, self.group))
         self.work[k] = dist.batch_isend_irecv(ops) if ops else []
@@ -149,6 +153,8 @@ class FrameScatterPipe:
             w.wait()
         if self.xbuf is not None and len(self.mine):
             self.buf[k][:len(self.mine)].copy_(self.xbuf[k][:len(self.mine)], non_blocking=True)
+            self.up_ev[k] = torch.cuda.Event()
+            self.up_ev[k].record(torch.cuda.current_stream(self.buf[k].device))
         if self.buf[k].is_cuda:
             cur = torch.cuda.current_stream(self.buf[k].device)
             if self.consumer is not None and self.consumer.get_stream():

@@ -45,7 +45,7 @@ class Position(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("steps", C.c_int64), ("mog_ms", C.c_double), ("morph_ms", C.c_double),
                 ("blob_ms", C.c_double), ("total_ms", C.c_double), ("event_pair_ms", C.c_double),
-                ("mog_frames", C.c_int64)]
+                ("mog_frames", C.c_int64), ("dropped", C.c_int64)]
 
 
 class Traffic(C.Structure):
@@ -56,7 +56,7 @@ class Traffic(C.Structure):
 
 E_RING_FULL = -4
 E_RING_EMPTY = -5
-ABI_VERSION = 8          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
+ABI_VERSION = 9          # must equal OATGPU_ABI_VERSION of include/oatgpu.h
 TAP_THRESHOLD, TAP_MORPH, TAP_FINAL = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)

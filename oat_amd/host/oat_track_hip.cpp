@@ -27,10 +27,16 @@
 // and every shard is a batched tracker of its own (own device context, own thread, own loop): streams are
 // independent, so nothing crosses between shards.  The same device may be named twice (two contexts on one GPU).
 //
+// --ingest-root D0 (with --gpu-index D0,D1,...): every camera's frame is ingested on device D0 and travels to the device that
+// owns its stream over RCCL send/recv (scatter_tracker.hpp; north_star's "RCCL over xGMI only for the trivial stream-to-rank
+// scatter") -- one process, one thread, the same partition.  Without it every shard ingests its own cameras (the realistic
+// camera topology).
+//
 // --thresh [lo,hi] selects the GREY chain instead:  framefilt mog -> posidet thresh  on SOURCEs that carry GREY
 // frames (a mono camera or `framefilt col -C GREY`; SimpleThreshold.cpp:46 requires them), the one-channel model
 // and the intensity window of SimpleThreshold.cpp:171-174 in the same fused launches.
 #include "component.hpp"
+#include "scatter_tracker.hpp"
 #include <chrono>
 #include <deque>
 #include <fstream>
@@ -325,11 +331,14 @@ int main(int argc, char **argv)
                          "       [--homography [h11,h12,...,h33]]   posifilt homography fused in (positions in world units)\n"
                          "       [--kalman [--dt s] [-T|--timeout s] [--sigma-accel a] [-n|--sigma-noise n]]   (posifilt kalman fused in)\n"
                          "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n"
-                         "--gpu-index N0,N1,..: the cameras are split into contiguous blocks, one per listed device (own context and thread).\n";
+                         "--gpu-index N0,N1,..: the cameras are split into contiguous blocks, one per listed device (own context and thread).\n"
+                         "--ingest-root D0 (with --gpu-index D0,D1,..): all frames are ingested on device D0 and scattered to their devices\n"
+                         "       over RCCL send/recv (one process, one thread); --timing prints bytes per peer and ms per step.\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
-                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy", "timing"}, {"kalman", "timing"});
+                        "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy", "timing",
+                        "ingest-root"}, {"kalman", "timing"});
         const std::vector<std::string> sources = split_list(o.positional[0]), sinks = split_list(o.positional[1]);
         if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
         // --gpu-index N | N0,N1,...: one shard of the SOURCE list per listed device (contiguous blocks)
@@ -339,6 +348,22 @@ int main(int argc, char **argv)
             const long v = strtol(d.c_str(), &end, 10);
             if (!end || *end || v < 0 || v > 1023) throw std::runtime_error("--gpu-index: expected N or N0,N1,... (device ordinals)");
             devices.push_back((int)v);
+        }
+        if (o.has("ingest-root")) {                                       // the stream-to-rank scatter over RCCL (scatter_tracker.hpp)
+            for (const char *k : {"kalman", "thresh", "mask", "model-file", "homography", "stage-copy"})
+                if (o.has(k)) throw std::runtime_error(std::string("--ingest-root does not take --") + k);
+            ScatterTracker t(sources, sinks, devices, (int)o.num("ingest-root", 0, 0, 1023));
+            t.learning_coeff_ = o.num("adaptation-coeff", 0.0, 0.0, 1.0);
+            double a, b;
+            if (o.arr2("h-thresh", a, b)) { t.cfg_.h_lo = (int)a; t.cfg_.h_hi = (int)b; }
+            if (o.arr2("s-thresh", a, b)) { t.cfg_.s_lo = (int)a; t.cfg_.s_hi = (int)b; }
+            if (o.arr2("v-thresh", a, b)) { t.cfg_.v_lo = (int)a; t.cfg_.v_hi = (int)b; }
+            if (o.has("erode")) t.cfg_.erode = (int)o.num("erode", 0, 0, 1e6);
+            if (o.has("dilate")) t.cfg_.dilate = (int)o.num("dilate", 0, 0, 1e6);
+            if (o.arr2("area", a, b)) { t.cfg_.min_area = a; t.cfg_.max_area = b; }
+            t.cfg_.ring_depth = (int)o.num("ring", 2, 2, 64);
+            t.timing_ = o.has("timing");
+            return t.run();
         }
         const int S = (int)sources.size(), N = (int)devices.size(), per = (S + N - 1) / N;
         std::vector<std::unique_ptr<BatchedTracker>> shards;

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_default_config(lib):
     from oat_amd import ffi
-    assert lib.oatgpu_abi_version() == ffi.ABI_VERSION == 8
+    assert lib.oatgpu_abi_version() == ffi.ABI_VERSION == 9
     cfg = ffi.Config()
     assert lib.oatgpu_default_config(C.byref(cfg)) == 0
     # cv::createBackgroundSubtractorMOG2() defaults + HSVDetector.h:77-94

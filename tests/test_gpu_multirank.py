@@ -137,6 +137,12 @@ def test_the_drivers_own_multi_gpu_command_yields_the_whole_record_on_one_gpu():
     t0 = time.perf_counter()
     r = _launch(cmd, env, 900)
     wall = time.perf_counter() - t0
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "drivers_multi_gpu_command_stderr.txt"), "w") as f:
+            f.write(r.stderr[-60000:])
+    except OSError:
+        pass
     assert r.returncode == 0, r.stderr[-3000:]
     assert wall < 900
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

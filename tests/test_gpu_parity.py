@@ -1422,6 +1422,54 @@ def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
     assert [hp.collect(), hp.collect()] == [ref.collect(), ref.collect()]
 
 
+@pytest.mark.parametrize("shape", [(2160, 3840, 1), (1080, 1920, 2)])
+def test_early_order_survives_a_tool_that_serialises_dispatches(shape):
+    """the default path of ONE stream of >= 4 MP (and of two 1080p streams) parks a blob workgroup that
+    waits on the device for a ticket a later kernel publishes -- two kernels resident at once, which HIP does not promise.
+    A child process runs 44 frames through that path with the ring kept full under everything that serialises dispatches
+    here: AMD_SERIALIZE_KERNEL=3, HIP_LAUNCH_BLOCKING=1, and a counter-collecting rocprofv3 (the tool that produced the
+    100 ms waits in round 4).  Whatever the runtime does with the parked workgroup: one result per frame, in order
+    (PositionDetector.cpp:58-99), every one identical to the oracle's, the whole model too; at most ONE time-out episode,
+    after which the context has switched the early order off and says so; and the run is not slower than a single 100 ms
+    wait explains."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    rows, cols, n = shape
+    child = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "children", "early_fallback_child.py"),
+             str(rows), str(cols), str(n), "44"]
+    base = {k: v for k, v in os.environ.items() if k not in ("AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")}
+    modes = [("plain", {}, []), ("AMD_SERIALIZE_KERNEL=3", {"AMD_SERIALIZE_KERNEL": "3"}, []), ("HIP_LAUNCH_BLOCKING=1", {"HIP_LAUNCH_BLOCKING": "1"}, [])]
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    tmp = tempfile.mkdtemp(prefix="oat_early_", dir="/tmp")
+    if os.path.exists(prof):
+        modes.append(("rocprofv3 --pmc", {"TMPDIR": "/tmp"}, [prof, "--kernel-trace", "--pmc", "SQ_WAVES", "-d", tmp, "-o", "r", "--"]))
+    seen = {}
+    try:
+        for name, env, prefix in modes:
+            r = subprocess.run(prefix + child, env=dict(base, **env), cwd="/tmp", capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            seen[name] = j
+            assert j["results"] == 44 and j["mismatches"] == [] and j["model_ok"], (name, j)
+            assert j["timeouts"] <= 1, (name, j)
+            if j["timeouts"]:
+                assert "early blob dispatch switched off" in j["last_error"], (name, j)
+                assert j["early_steps"] < j["steps"], (name, j)            # the steps behind the episode took the plain order
+            assert j["wall_s"] < (2.0 if not prefix else 30.0) + 0.15 * j["timeouts"], (name, j)    # (a profiler's own cost aside)
+        assert seen["plain"]["timeouts"] == 0 and seen["plain"]["early_steps"] >= 40, seen["plain"]   # the path under test IS the default
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        try:
+            os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                   "early_fallback_%dx%dx%d.json" % shape), "w") as f:
+                json.dump(seen, f, indent=1)
+        except OSError:
+            pass
+
+
 # ------------------------------------------- two frames a launch (temporal fusion) --
 
 def test_two_one_stream_contexts_on_the_default_early_path_interleaved(A):
@@ -1943,7 +1991,7 @@ def test_device_count_and_numa_node(A):
 def test_paired_back_half_equals_one_frame_a_launch_and_the_oracle(A, ring, geom):
     """Round 5: outside the early order both frames of a two-frame step share ONE row-scan launch and ONE k_blob_lds launch
     (grid z = frame; steps alternate between two B streams with two scratch sets each).  Quiet and BUSY frames (busy = the LDS
-    kernel declines the frame -> repaired by the global kernels in the frame's own scratch set; then the plain order until
+    kernel declines the frame -> repaired by the global kernels in the REPAIR set (scratch set 4, on B2); then the plain order until
     the streak is back -> a switch of paths with a drain), even and odd ring depths, one and several streams, an odd number of
     frames (the last one goes out alone): every result equals one frame a launch (the per-frame plain order) and the oracle;
     the step shape query says what ran."""
@@ -2032,5 +2080,12 @@ def test_abi8_plumbing_k1_workgroup_latency_sequence_and_open_retries(A):
     assert all(e[i] <= d[i] for i in range(n)) and d == sorted(d) and e == sorted(e) and e[0] >= 0.0
     assert all(e[i + 4] >= d[i] for i in range(n - 4))              # ring depth 4: frame i + 4 is handed over after frame i was collected
     assert [(o.valid, o.a00) for o in out] == [(v, a) for v, a, *_ in outs[0]]
-    assert hp.lib.oatgpu_device_open_retries() == 0
+    # (the counter is the process's: >= 0, and it does not move while this context -- long since open -- works; a sibling process
+    # opening the device at the same instant is exactly what the retry absorbs, so "== 0" was the wrong assertion: ADVICE r05)
+    r0 = hp.lib.oatgpu_device_open_retries()
+    assert r0 >= 0
+    hp.track_dev(frames[0].data_ptr())
+    assert hp.lib.oatgpu_device_open_retries() == r0
+    p = hp.profile_read()
+    assert set(p) >= {"steps", "mog_ms", "mog_frames", "dropped"} and p["dropped"] == 0          # (profiling was never on here)
     hp.close()

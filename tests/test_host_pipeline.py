@@ -320,7 +320,7 @@ sigma-noise = 1
 
 # ------------------------------------------------- batched, pipelined tracker --
 
-def _run_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200):
+def _run_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200, tracker_stderr=None):
     """n feeders -> ONE oat-track-hip (n SOURCEs, n SINKs, one context, one launch per stage) -> n readers."""
     n = len(streams_frames)
     rows, cols = streams_frames[0][0].shape[:2]
@@ -333,7 +333,7 @@ def _run_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200)
     readers = [subprocess.Popen([B("oat-posi-cout"), a], stdout=f, text=True) for a, f in zip(snks, files)]
     tracker = subprocess.Popen([B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
-                                "--ring", str(ring)] + list(extra))
+                                "--ring", str(ring)] + list(extra), stderr=tracker_stderr)
     _consumers_ready(*srcs, *snks)
     feeders = []
     for s in range(n):
@@ -442,6 +442,41 @@ def test_batched_tracker_sharded_over_device_contexts(host_bins, tmp_path, ncam,
                 hits += 1
                 assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
         assert hits >= n - 3, (s, hits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncam", [1, 3])
+def test_ingest_root_scatter_tracker_world_of_one_matches_the_oracle(host_bins, tmp_path, ncam):
+    """`oat-track-hip --ingest-root 0 --gpu-index 0`: the stream-to-rank scatter behind the C++ boundary --
+    ONE process, ncclCommInitAll over the listed devices, per step every camera's frame into the root device's staging slot,
+    ncclGroupStart / ncclSend x (N - 1) / ncclRecv / ncclGroupEnd on transfer streams, every shard's context ordered behind its
+    transfer by an event, slot reuse gated by oatgpu_track_input_consumed (oat_amd/host/scatter_tracker.hpp).  Here the world
+    of one there is hardware for: the communicator is created for real, the root's block is consumed in place, every camera
+    equals ITS oracle token by token in order (PositionDetector.cpp:58-99), and --timing reports bytes per peer and ms per
+    step.  N > 1 is the same code with the sends in it: unverified until a multi-GPU node runs it."""
+    import oracle_lib as O
+    from oat_amd.synth import SyntheticStream
+    rows, cols, n = 240, 320, 24
+    streams = [SyntheticStream(rows, cols, 70 + s, n_discs=1, radius=8 + 3 * s) for s in range(ncam)]
+    frames = [[st.frame(t, with_discs=t > 0) for t in range(n)] for st in streams]
+    err = tmp_path / "tracker.err"
+    with open(err, "w") as ef:
+        got = _run_batched(host_bins, tmp_path, frames, ring=2, extra=("--gpu-index", "0", "--ingest-root", "0", "--timing"), tracker_stderr=ef)
+    p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=7, min_area=20.0, max_area=1e5)
+    for s in range(ncam):
+        assert len(got[s]) == n, (s, len(got[s]))
+        orc = O.Mog2(rows, cols, 3)
+        hits = 0
+        for t, (f, g) in enumerate(zip(frames[s], got[s])):
+            want, _ = O.chain_step(orc, f, 0.01, p)
+            assert g["tick"] == t + 1 and g["pos_ok"] == want["valid"], (s, t, g)
+            if want["valid"]:
+                hits += 1
+                assert abs(g["pos_xy"][0] - want["x"]) < 1e-4 and abs(g["pos_xy"][1] - want["y"]) < 1e-4, (s, t)
+        assert hits >= n - 3, (s, hits)
+    text = open(err).read()
+    assert "track-scatter[" in text and "RCCL" in text and f"{ncam * rows * cols * 3} bytes per peer and step" in text, text[-600:]
+    assert f"{n} steps, {ncam} cameras over 1 device(s)" in text, text[-600:]
 
 
 def _start_batched(host_bins, tmp_path, streams_frames, extra=(), ring=2, fps=200):

@@ -9,3 +9,5 @@ echo "== files named *opencv* / cv2*"; find / -xdev \( -iname "*opencv*" -o -ina
 echo "== other image libraries"; for m in skimage scipy.ndimage PIL torchvision; do python -c "import $m; print('$m', getattr($m,'__version__',''))" 2>&1 | tail -1; done
 /opt/conda/bin/python3.9 -c "import skimage, scipy; print('conda3.9 skimage', skimage.__version__, 'scipy', scipy.__version__)" 2>&1 | tail -1
 echo "== host"; nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2
+# ... and if there is one, keep what it says: fixtures for tests/golden/, consumed by tests/test_oracle_golden.py
+echo "== harvest"; python "$(dirname "$0")/harvest_opencv_golden.py" --out gpurun_out/opencv_golden 2>&1 | tail -8
