@@ -743,10 +743,13 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
     from oat_amd.components import Position2D
     hp = leg.hp
     min_ms = MIN_TIMED_MS if min_ms is None else min_ms
+    tag = f"[{leg.name} r{os.environ.get('RANK', '0')}]"
     leg.init()
     aged = leg.age(age_frames) if age_frames > 0 else 0
+    log(tag, f"aged {aged} frames")
     models = leg.export_models() if export else None
     handover = leg.step                 # first frame the oracle will see after taking the models over
+    log(tag, "models exported" if export else "no export")
     if spin > 0 and spin_args:
         spin_up(*spin_args, spin)       # the export left the device idle: warm it again, on a scratch context
     if W:
@@ -787,6 +790,7 @@ def timed_run(leg, K, W, barrier, prof_every, age_frames, export=True, spin=0.0,
         out = leg.run(n, prepared, keep=True, done_s=done, enq_s=enq)
         barrier()
         elapsed = time.perf_counter() - t0
+        log(tag, f"timed region: {R} blocks x {K} steps in {elapsed * 1e3:.1f} ms (attempt {attempts})")
         prof = hp.profile_read()
         hp.profile(0)
         short = [elapsed * 1e3 < min_ms]
@@ -1433,6 +1437,7 @@ def main():
 
     leg = Leg(args.workload, local_rank, rank, dense=args.dense_model, pool=10 if args.dense_model else args.pool,
               input_mode=args.input)
+    log(f"[rank {rank}] device open, {args.pool}-frame pool of {args.workload} resident")
 
     def barrier():
         leg.hp.synchronize()
@@ -1487,6 +1492,7 @@ def main():
     else:
         n_found = n_found_local
 
+    log(f"[rank {rank}] timed run and probes done")
     k1_wg_benched, early_benched = leg.hp.last_step_shape()
     early_timeouts = leg.hp.early_blob_timeouts()
     one_lat = None

@@ -1,33 +1,15 @@
 #!/bin/bash
-# Dynamic instruction profile of k_mog_fused by truncation, on the GPU box:  tools/cut_profile.sh OUT [--fusion1] [--dense]
-# needs the variants liboatgpu_cut1.so .. liboatgpu_cut5.so and liboatgpu_base.so (make variant NAME=cutN DEFS=-DOATGPU_CUT=N)
-out=$1; shift
+# Dynamic vector / scalar instructions a wave of k_mog_fused by region (tools/cut_profile.py): tools/cut_profile.sh OUT [--fusion1]
+# needs build/variants/liboatgpu_cut{1..5}.so and liboatgpu_meas.so (make variant NAME=cut$n DEFS=-DOATGPU_CUT=$n; make variant NAME=meas)
+out=${1:-gpurun_out/cut}; shift
 R=$PWD; mkdir -p $R/$out
-mkdir -p /tmp/cut_state; python tools/cut_profile.py save "$@" /tmp/cut_state > /dev/null 2>&1
+python tools/cut_profile.py save $R/$out/model > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-{
-echo "| cut | up to | VALU / wave | SALU / wave | VMEM rd / wave | us |"
-echo "|---|---|---|---|---|---|"
-for n in 1 2 3 4 5 base; do
-  lib=$R/build/variants/liboatgpu_cut$n.so; [ $n = base ] && lib=$R/build/variants/liboatgpu_base.so
-  rm -rf /tmp/cutp
-  OATGPU_MEASURE_PY=1 OATGPU_LIB=$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d /tmp/cutp -o r -- python $R/tools/cut_profile.py run "$@" /tmp/cut_state > /dev/null 2> /tmp/cutp.err || tail -2 /tmp/cutp.err
-  db=$(find /tmp/cutp -name "*.db" | head -1)
-  python - $db $n <<'PY'
-import sqlite3, sys
-db = sqlite3.connect(sys.argv[1])
-rows = db.execute("select kernel_name, counter_name, value, duration from counters_collection order by start").fetchall()
-per = {}
-for k, c, v, d in rows:
-    if "k_mog_fused" in k:
-        per.setdefault(c, []).append((v, d))
-names = {"1": "phase 1 + mode 0", "2": "+ phase 2 (masks, zero-inits, loads)", "3": "+ modes 1..4", "4": "+ finish (renormalise, new mode)",
-         "5": "+ HSV / inRange (and all of frame 2 with two frames a launch)", "base": "+ stores (the whole kernel)"}
-def avg(c):
-    l = per.get(c, [])[8:]
-    return (sum(v for v, _ in l) / len(l), sum(d for _, d in l) / len(l) / 1e3) if l else (0, 0)
-w = avg("SQ_WAVES")[0] or 1
-print(f"| {sys.argv[2]} | {names[sys.argv[2]]} | {avg('SQ_INSTS_VALU')[0] / w:.1f} | {avg('SQ_INSTS_SALU')[0] / w:.1f} | {avg('SQ_INSTS_VMEM_RD')[0] / w:.2f} | {avg('SQ_INSTS_VALU')[1]:.1f} |")
-PY
+for v in cut1 cut2 cut3 cut4 cut5 meas; do
+  rm -rf /tmp/cp_$v
+  OATGPU_MEASURE_PY=1 OATGPU_LIB=$R/build/variants/liboatgpu_$v.so timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d /tmp/cp_$v -o r -- python $R/tools/cut_profile.py run "$@" $R/$out/model > /dev/null 2> /tmp/cp_$v.err || tail -3 /tmp/cp_$v.err
+  db=$(find /tmp/cp_$v -name "*.db" | head -1)
+  echo "## $v" >> $R/$out/cut.md
+  [ -n "$db" ] && python $R/profiles/summarize_pmc.py $db k_mog_fused 8 >> $R/$out/cut.md
 done
-} | tee $R/$out/cut_profile.md
+cat $R/$out/cut.md
