@@ -142,7 +142,11 @@ int oatgpu_abi_version(void);
 int oatgpu_default_config(oatgpu_config *cfg);
 
 /* Object lifetime == the reference component's (MOG model and scratch are
- * members: BackgroundSubtractorMOG.h:72-73, HSVDetector.h:83). */
+ * members: BackgroundSubtractorMOG.h:72-73, HSVDetector.h:83).
+ * Device memory, all of it allocated HERE (an out-of-memory is OATGPU_E_NOMEM from oatgpu_create, never a failure in the middle of a
+ * pipelined step): per camera stream and pixel 101 B of model + 150 B of back-half scratch (five sets of 30 B: three launch orders'
+ * worth plus the repair set) + ring_depth / 8 B of threshold words + the staging frame; 1080p: 0.52 GB a stream, 4K: 2.1 GB.  The
+ * host-frame path (oatgpu_track_enqueue / _stage) adds ring_depth staging frames on first use. */
 oatgpu_ctx *oatgpu_create(const oatgpu_config *cfg);   /* NULL on failure; oatgpu_last_error(NULL) */
 void oatgpu_destroy(oatgpu_ctx *ctx);
 const char *oatgpu_last_error(const oatgpu_ctx *ctx);
