@@ -586,11 +586,18 @@ def make_pool_device(rows, cols, ns, nframes, rank, dev):
                            fx=0.013 * (1 + d) + 0.002 * (s % 7), fy=0.017 * (1 + 0.5 * d) + 0.001 * (s % 5),
                            px=cpu_rng.uniform(0, 6.28), py=cpu_rng.uniform(0, 6.28)))
         discs.append(ds)
-    pool = []
+    # ONE allocation for the whole pool and no boolean-mask indexing (a `nonzero` = a device synchronisation each): eight ranks
+    # sharing one device (the `--backend gloo` smoke form of an N-GPU run) spent TEN MINUTES here with 48 frames a rank -- 0.3 to
+    # 18 s as plain processes, 1 000 s under the launcher, 1 s with 24 frames (profiles/r08_gpus8_startup.txt); the bytes are
+    # the same as before.
+    flick_add = [flick.unsqueeze(-1).to(torch.int16) * v for v in (-50, 60)]                   # (rows, cols, 1), by frame parity
+    cols_dev = {tuple(c): torch.tensor(c, device=dev, dtype=torch.uint8) for c in DISC_BGR}
+    store = torch.empty((nframes, ns, rows, cols, 3), device=dev, dtype=torch.uint8)
     for t in range(nframes):
         f = base.unsqueeze(0) + torch.randint(-6, 7, (ns, rows, cols, 3), device=dev, dtype=torch.int16, generator=g)
-        f[:, flick] += 60 if (t & 1) else -50
-        f = f.clamp_(0, 255).to(torch.uint8)
+        f += flick_add[t & 1]
+        torch.clamp(f, 0, 255, out=f)
+        store[t].copy_(f)
         if t > 0:                                   # frame 0 (model initialisation) has no discs
             for s in range(ns):
                 for d in discs[s]:
@@ -599,10 +606,9 @@ def make_pool_device(rows, cols, ns, nframes, rank, dev):
                     r = d["r"]
                     y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, rows), max(cx - r, 0), min(cx + r + 1, cols)
                     m = ((xx[:, x0:x1] - cx) ** 2 + (yy[y0:y1] - cy) ** 2) <= r * r
-                    sub = f[s, y0:y1, x0:x1]
-                    sub[m] = torch.tensor(d["col"], device=dev, dtype=torch.uint8)
-        pool.append(f.contiguous())
-    return pool
+                    sub = store[t, s, y0:y1, x0:x1]
+                    sub.copy_(torch.where(m.unsqueeze(-1), cols_dev[tuple(d["col"])], sub))
+    return [store[t] for t in range(nframes)]
 
 
 class Leg:

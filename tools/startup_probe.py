@@ -18,6 +18,14 @@ def lap(k):
 sys.path.insert(0, %r)
 import torch
 lap("import torch")
+if os.environ.get("PROBE_GLOO"):
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    lap("gloo init")
+if os.environ.get("PROBE_PIN"):
+    import bench as _b
+    _b.pin_to_gpu_node(0)
+    lap("pin to the GPU's NUMA node (%%d cpus)" %% len(os.sched_getaffinity(0)))
 torch.cuda.set_device(0)
 x = torch.empty(1 << 20, device="cuda"); torch.cuda.synchronize()
 lap("first allocation")
@@ -41,6 +49,10 @@ print(json.dumps(dict(rank=int(os.environ.get("RANK", "0")), **T)), flush=True)
 
 
 def main():
+    if os.environ.get("PROBE_CHILD"):            # under torch.distributed.run: this process IS a rank
+        sys.argv = [sys.argv[0], sys.argv[1] if len(sys.argv) > 1 else "48"]
+        exec(CHILD)
+        return
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     pool = sys.argv[2] if len(sys.argv) > 2 else "48"
     t0 = time.perf_counter()
