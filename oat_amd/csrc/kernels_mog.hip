@@ -151,28 +151,10 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
         bool fit_here = false;
         if (!c.fits) {
             const float var = rv(s, MODE);
-#if defined(OATGPU_PK)                  // lab (tools/patches): the record's aligned register pairs {var, m0} / {m1, m2} through packed fp32 ops
-            float d0, d1, d2, dist2;
-            if constexpr (TUP) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 lo = {s.r[MODE][0], s.r[MODE][1]}, hi = {s.r[MODE][2], s.r[MODE][3]};
-                const f32x2 xa = {0.f, x0}, xb = {x1, x2};
-                const f32x2 da = lo - xa, db = hi - xb;
-                const f32x2 sa = da * da, sb = db * db;
-                d0 = da.y; d1 = db.x; d2 = db.y;
-                dist2 = sa.y + sb.x + sb.y;
-            } else {
-                d0 = rm<0>(s, MODE) - x0;
-                d1 = CH == 3 ? rm<1>(s, MODE) - x1 : 0.f;
-                d2 = CH == 3 ? rm<2>(s, MODE) - x2 : 0.f;
-                dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
-            }
-#else
             const float d0 = rm<0>(s, MODE) - x0;
             const float d1 = CH == 3 ? rm<1>(s, MODE) - x1 : 0.f;
             const float d2 = CH == 3 ? rm<2>(s, MODE) - x2 : 0.f;
             const float dist2 = CH == 3 ? d0 * d0 + d1 * d1 + d2 * d2 : d0 * d0;
-#endif
             if (c.total < P.TB && dist2 < P.Tb * var) c.background = true;
             if (dist2 < P.Tg * var) {
                 c.fits = true;
@@ -190,19 +172,7 @@ __device__ __forceinline__ void mog2_mode(PxModel<CH, TUP> &s, PxLoop &c, float 
                 if (upd) {
                 const float k = rate_over_weight<FROZEN>(alphaT, weight);
                 const float o0 = rm<0>(s, MODE), o1 = CH == 3 ? rm<1>(s, MODE) : 0.f, o2 = CH == 3 ? rm<2>(s, MODE) : 0.f;
-#if defined(OATGPU_PK)
-                float n0, n1, n2;
-                if constexpr (TUP) {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 kk = {k, k}, dd = {d1, d2}, oo = {o1, o2};
-                    const f32x2 nn = oo - kk * dd;
-                    n0 = o0 - k * d0; n1 = nn.x; n2 = nn.y;
-                } else {
-                    n0 = o0 - k * d0; n1 = CH == 3 ? o1 - k * d1 : 0.f; n2 = CH == 3 ? o2 - k * d2 : 0.f;
-                }
-#else
                 const float n0 = o0 - k * d0, n1 = CH == 3 ? o1 - k * d1 : 0.f, n2 = CH == 3 ? o2 - k * d2 : 0.f;
-#endif
                 set_rm<0>(s, MODE, n0);
                 if (CH == 3) { set_rm<1>(s, MODE, n1); set_rm<2>(s, MODE, n2); }
                 float varnew = var + k * (dist2 - var);
@@ -693,9 +663,6 @@ __global__ __launch_bounds__(WG, (k1_waves<CH, AUDIT, NTLD, NF>())) void k_mog_f
 #pragma unroll
     for (int k = 0; k < kMaxMix; ++k) {
         pm.w[k] = 0.f;
-#if defined(OATGPU_UNDEF_INIT)          // lab (tools/patches): the records of slots >= 1 start as whatever their registers hold (r03's experiment, re-measured)
-        if constexpr (TUP) { if (k >= 1) { asm volatile("" : "=v"(pm.r[k])); continue; } }
-#endif
         set_rv(pm, k, 0.f); set_rm<0>(pm, k, 0.f); set_rm<1>(pm, k, 0.f); set_rm<2>(pm, k, 0.f);
     }
     int cnt = 0;
