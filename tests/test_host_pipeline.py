@@ -49,6 +49,20 @@ def test_binaries_exist_and_print_usage(host_bins):
     assert r.returncode == 255 and "Selected TYPE is invalid." in r.stderr
 
 
+def test_ingest_root_arguments_are_checked_before_any_device_is_touched(host_bins):
+    """`oat-track-hip --ingest-root` (scatter_tracker.hpp): the root must be one of --gpu-index, every device once (one RCCL
+    rank per device), and the options of the other fused stages are refused -- exit code -1 and the reason on stderr
+    (framefilter/main.cpp:278-295), no GPU needed to say so."""
+    B = os.path.join(host_bins, "oat-track-hip")
+    for extra, msg in ((["--gpu-index", "0,1", "--ingest-root", "2"], "root device must be one of --gpu-index"),
+                       (["--gpu-index", "0,0", "--ingest-root", "0"], "every device of --gpu-index once"),
+                       (["--gpu-index", "0", "--ingest-root", "0", "--kalman"], "--ingest-root does not take --kalman")):
+        r = subprocess.run([B, "a,b", "c,d"] + extra, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 255 and msg in r.stderr, (extra, r.returncode, r.stderr)
+    r = subprocess.run(["ldd", B], capture_output=True, text=True)
+    assert "librccl" in r.stdout and "libamdhip64" in r.stdout and "liboatgpu" in r.stdout, r.stdout      # RCCL behind the C++ boundary
+
+
 def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
     """Token discipline of the transport alone: N frames in -> N tokens seen, in order."""
     # a Position2D-typed reader must refuse a Frame node (Source<T> type check)
