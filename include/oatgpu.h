@@ -131,7 +131,7 @@ typedef struct oatgpu_profile {
                                   besides kernel execution); measured at profile_enable */
     int64_t mog_frames;        /* frames the `steps` measured launches of the fused kernel covered
                                   (steps .. 2 * steps, see oatgpu_set_fusion)              */
-    int64_t dropped;           /* samples left out: their per-pixel launch read more than 8 x the running average -- a host
+    int64_t dropped;           /* samples left out: their per-pixel launch read more than 8 x the running average and 1 ms above it -- a host
                                   thread descheduled between the event record and the launch call puts its absence into the
                                   pair; at most 4 in a row (a 5th is a change of regime and is taken)  */
 } oatgpu_profile;

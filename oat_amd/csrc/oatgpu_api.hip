@@ -1301,7 +1301,10 @@ static void prof_fold(oatgpu_ctx *c)
         // (the drops are COUNTED -- oatgpu_profile.dropped -- and bounded: four in a row are no host hiccup but a
         // change of regime, e.g. one-frame steps on a sparse model followed by two-frame steps on a dense one; the sample is
         // then taken and the streak starts anew, so the profile cannot freeze on its first eight samples.)
-        if (c->prof_sum.steps >= 8 && a > 8.0 * (c->prof_sum.mog_ms / (double)c->prof_sum.steps) && c->prof_drop_streak < 4) {
+        // ... and a host stall is a millisecond or more: on a 70 x 200 frame, whose launch takes 5 us, ordinary jitter is "eight
+        // times the average" (a dropped sample failed test_two_frames_a_launch_... once in this round's runs)
+        const double mean_ms = c->prof_sum.steps ? c->prof_sum.mog_ms / (double)c->prof_sum.steps : 0.0;
+        if (c->prof_sum.steps >= 8 && a > 8.0 * mean_ms && a > mean_ms + 1.0 && c->prof_drop_streak < 4) {
             c->prof_sum.dropped += 1;
             c->prof_drop_streak++;
             continue;

@@ -1579,8 +1579,9 @@ def test_two_frames_a_launch_equals_one_frame_a_launch(A, ch, restore, ring):
             got.append(hp.collect())
         prof = hp.profile_read()
         # fusion 2: frame 1 initialises the model (alone), then pairs, an odd one at the end
-        assert prof["mog_frames"] == nframes
-        assert prof["steps"] == (nframes if fusion == 1 else 1 + (nframes - 1) // 2 + (nframes - 1) % 2), prof
+        # (a sample the profile took for a host stall -- oatgpu_profile.dropped -- is a step it does not count)
+        assert nframes - 2 * prof["dropped"] <= prof["mog_frames"] <= nframes, prof
+        assert prof["steps"] + prof["dropped"] == (nframes if fusion == 1 else 1 + (nframes - 1) // 2 + (nframes - 1) % 2), prof
         runs[fusion] = (got, [hp.mog_state(s) for s in range(n)], hp.read_mask(1, 0))
         hp.close()
     orcs = [O.Mog2(rows, cols, ch, params=dict(restore_nmodes=restore)) for _ in range(n)]
