@@ -217,13 +217,18 @@ protected:
         for (int k = 0; k < N_; ++k) gpu_[k]->check(oatgpu_track_input_consumed(gpu_[k]->ctx));
         OAT_LAP(t_gate_);
         // ---- scatter: block k of the root's slot -> device k, all peers in one group ----
+        // (the gate's library calls left the LAST shard's device current: every call below names its device first -- the
+        // single-process form of RCCL's group calls is `set device i; ncclXxx(.., comm[i], stream[i])`)
+        OAT_HIP(hipSetDevice(devices_[root_]));
         OAT_HIP(hipStreamWaitEvent(xfer_[root_], ev_in_[q], 0));
         if (N_ > 1) {
             OAT_NCCL(ncclGroupStart());
             for (int k = 0; k < N_; ++k) {
                 if (k == root_ || !block_len(k)) continue;
                 const size_t bytes = (size_t)block_len(k) * frame_bytes_;
+                OAT_HIP(hipSetDevice(devices_[root_]));
                 OAT_NCCL(ncclSend(stage_[q] + (size_t)block_begin(k) * frame_bytes_, bytes, ncclUint8, k, comm_[root_], xfer_[root_]));
+                OAT_HIP(hipSetDevice(devices_[k]));
                 OAT_NCCL(ncclRecv(block_[k][q], bytes, ncclUint8, root_, comm_[k], xfer_[k]));
             }
             OAT_NCCL(ncclGroupEnd());
