@@ -59,7 +59,7 @@ def batched(a):
     tracker = subprocess.Popen((a.tracker_prefix.split() if a.tracker_prefix else []) +
                                [B("oat-track-hip"), ",".join(srcs), ",".join(snks), "-a", "0.01", "--area", "[20,100000]",
                                 "-H", "[100,125]", "-S", "[150,256]", "-V", "[100,256]", "-e", "3", "-d", "7",
-                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []),
+                                "--ring", str(a.ring)] + (["--stage-copy", a.stage_copy] if a.stage_copy else []) + (["--timing"] if a.timing else []) + a.tracker_extra.split(),
                                stderr=terr)
     time.sleep(12.0 if a.tracker_prefix else 4.0)
     t0 = time.perf_counter()
@@ -89,7 +89,7 @@ def batched(a):
         terr.close()
         os.unlink(terr.name)
         for l in txt.splitlines():
-            if "per round" in l:
+            if "per round" in l or "per step (ms)" in l:
                 print(l)
                 m = re.search(r"steady ([0-9.]+) fps", l)
                 if m:
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cameras", type=int, default=1)
     ap.add_argument("--ring", type=int, default=2)
     ap.add_argument("--tracker-prefix", default="", help="command to run oat-track-hip under, e.g. 'rocprofv3 --memory-copy-trace -d /tmp/mc -o r --'")
+    ap.add_argument("--tracker-extra", default="", help="more oat-track-hip options, e.g. '--gpu-index 0 --ingest-root 0' (the RCCL scatter form)")
     ap.add_argument("--timing", action="store_true", help="oat-track-hip --timing: where the tracker's loop spends its wall clock")
     ap.add_argument("--stage-copy", default="", choices=["", "dma", "kernel"], help="oat-track-hip --stage-copy (oatgpu_set_stage_copy)")
     ap.add_argument("--feeder-node", type=int, default=-1,
