@@ -208,8 +208,11 @@ protected:
             src_pins_[s].pin(shm);
             samples[s] = shm.sample();
             OAT_HIP(hipMemcpyAsync(stage_[q] + (size_t)s * frame_bytes_, shm.data(), frame_bytes_, hipMemcpyHostToDevice, copy_));
+            (void)hipStreamQuery(copy_);             // submit NOW: ROCm 7.2 holds a queued copy back until something flushes its stream (oatgpu_track_stage)
         }
         OAT_HIP(hipEventRecord(ev_in_[q], copy_));
+        // (publishing the previous step's positions HERE, under the copies, was measured and is slower: 8 x 1080p 6.55 k -> 5.8-6.1 k
+        // fps -- the SINK hand-shakes and the copy engine's completion handling share this one thread; they leave behind the enqueue)
         OAT_HIP(hipEventSynchronize(ev_in_[q]));                 // the frames have left their segments ...
         for (int s = 0; s < S_; ++s) frame_sources_[s].post();  // ... the cameras may refill them (PositionDetector.cpp:78-86)
         OAT_LAP(t_ingest_);
