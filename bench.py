@@ -1054,28 +1054,34 @@ def scatter_leg(name, world, rank, dev, backend, steps, reduce_max, depth=2, gat
     return out
 
 
-def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_start, also=None):
-    """The scatter leg is the only part of an N > 1 run with a data-path exchange, and it runs LAST: should a transport hang
-    (a peer that died, a P2P path that does not come up), a timer ends the rank instead of the job's default 10-minute
-    collective timeout killing it without a line -- rank 0 first prints the line it already has, marked."""
+def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_start, also=None, extra_fn=None, want_scatter=True):
+    """The OPTIONAL legs of an N > 1 run -- the second workload on every rank (extra_fn, round 6) and the scatter legs, the only
+    part with a data-path exchange -- run LAST, behind the line's own measurements, under a timer: should a rank die in them or a
+    transport hang (a peer that died, a P2P path that does not come up), the timer ends the rank instead of the job's default
+    10-minute collective timeout killing it without a line -- rank 0 first prints the line it already has, marked.  The driver's
+    multi-GPU run is a one-shot: `value` must not depend on legs that come after it."""
     import threading
     done = threading.Event()
+    limit = args.scatter_timeout + (getattr(args, "extra_timeout", 240.0) if extra_fn else 0.0)
 
     def fire(why=None):
         if done.is_set():
             return
         done.set()
-        why = why or f"no result within {args.scatter_timeout} s"
-        log(f"[rank {rank}] scatter leg: {why} -- given up")
+        why = why or f"no result within {limit:.0f} s"
+        log(f"[rank {rank}] optional legs (second workload / scatter): {why} -- given up")
         if rank == 0 and line_so_far is not None:
-            line_so_far["scatter_ingest"] = dict(error=why, parity="timeout" if "within" in why else "error",
-                                                 backend=args.backend)
+            if want_scatter and not line_so_far.get("scatter_ingest"):
+                line_so_far["scatter_ingest"] = dict(error=why, parity="timeout" if "within" in why else "error",
+                                                     backend=args.backend)
+            if extra_fn and not line_so_far.get("extra_workloads") and also:
+                line_so_far["extra_workloads"] = {also: dict(name=also, value=None, parity="timeout" if "within" in why else "error")}
             line_so_far["bench_wall_s"] = time.perf_counter() - t_start
             emit(line_so_far)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
-    t = threading.Timer(args.scatter_timeout, fire)
+    t = threading.Timer(limit, fire)
     t.daemon = True
     t.start()
     # (a peer that DIES in the leg makes the launcher terminate the others: rank 0 then still hands over the line it has)
@@ -1085,11 +1091,27 @@ def scatter_with_watchdog(args, world, rank, dev, reduce_max, line_so_far, t_sta
         old_term = signal.signal(signal.SIGTERM, lambda *_: fire("terminated by the launcher (a peer died in the scatter leg)"))
     except ValueError:
         pass
+    if extra_fn:                         # the other north-star size on every rank, gated (multi_rank_extra)
+        try:
+            ex = extra_fn()
+        except Exception as e:
+            log(f"[rank {rank}] second workload failed:", e)
+            ex = dict(name=also, value=None, parity=f"error: {str(e)[-160:]}")
+        if rank == 0 and line_so_far is not None:
+            line_so_far["extra_workloads"] = {ex.get("name") or also: ex}
+    if not want_scatter:
+        done.set()
+        t.cancel()
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
+        return None
     try:
         sc = scatter_leg(args.workload, world, rank, dev, args.backend, args.scatter_steps, reduce_max)
     except Exception as e:
         log(f"[rank {rank}] scatter leg failed:", e)
         sc = dict(error=str(e)[-200:], parity="error", backend=args.backend)
+    if rank == 0 and line_so_far is not None:
+        line_so_far["scatter_ingest"] = sc          # (should the second scatter leg hang, the first one's result is in the line)
     if also:                             # the other workload's shard through the same scatter (fewer steps: it is the second leg)
         try:
             s2 = scatter_leg(also, world, rank, dev, args.backend, max(args.scatter_steps // 2, 12), reduce_max)
@@ -1396,6 +1418,7 @@ def main():
                                                               "the stream->rank scatter)")
     ap.add_argument("--scatter-steps", type=int, default=200, help="steps of the scatter_ingest leg (N > 1)")
     ap.add_argument("--scatter-timeout", type=float, default=150.0, help="seconds after which a hanging scatter leg is given up")
+    ap.add_argument("--extra-timeout", type=float, default=240.0, help="N > 1: seconds the second workload's leg adds to that limit")
     ap.add_argument("--dense-noise", type=int, default=5, help=argparse.SUPPRESS)   # lab: 3 keeps every dense pixel background (no shadow test)
     ap.add_argument("--lab-calm", action="store_true", help=argparse.SUPPRESS)   # kernel lab: SURVEY 8d input WITHOUT the flickering pixels
     args = ap.parse_args()
@@ -1524,17 +1547,19 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_rec)
 
-    # N > 1: the OTHER north-star size, every rank, gated (one invocation = the whole multi-GPU record)
-    extra_n = None
+    # N > 1: the OTHER north-star size, every rank, gated (one invocation = the whole multi-GPU record) -- run with the scatter
+    # legs, LAST and under their watchdog: nothing `value` needs comes after it
+    extra_fn = None
     other = "1080p8" if args.workload != "1080p8" else "4k1"
     if world > 1 and not args.no_extra and args.input == "device" and not args.dense_model:
-        extra_n = multi_rank_extra(other, K, W, local_rank, rank, world, reduce_max, args)
+        extra_fn = lambda: multi_rank_extra(other, K, W, local_rank, rank, world, reduce_max, args)
 
     if rank != 0:
         if world > 1:
-            if want_scatter:
+            if want_scatter or extra_fn:
                 leg.close()
-                scatter_with_watchdog(args, world, rank, dev, reduce_max, None, t_start, other if extra_n else None)
+                scatter_with_watchdog(args, world, rank, dev, reduce_max, None, t_start, also=other if extra_fn else None,
+                                      extra_fn=extra_fn, want_scatter=want_scatter)
             dist.barrier()              # rank 0 prints before everybody leaves
             dist.destroy_process_group()
         return
@@ -1922,8 +1947,6 @@ def main():
         line["extra_workloads"] = extra
         line["one_frame_a_launch"] = one_frame
         line["default_learning_rate_0"] = frozen
-    if extra_n:                                    # N > 1: the other north-star size, all ranks, gated
-        line["extra_workloads"] = {extra_n["name"]: extra_n}
 
     line["pipeline"] = None
     if solo and not args.no_pipeline and args.input == "device" and not args.dense_model:
@@ -1937,8 +1960,11 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.workload, pool_host0)
     else:
         line["cpu_baseline"] = None
-    if want_scatter:                               # last: nothing the line needs from the other ranks is still outstanding
-        line["scatter_ingest"] = scatter_with_watchdog(args, world, rank, dev, reduce_max, line, t_start, other if extra_n else None)
+    if want_scatter or extra_fn:                   # last: nothing the line needs from the other ranks is still outstanding
+        sc_ = scatter_with_watchdog(args, world, rank, dev, reduce_max, line, t_start, also=other if extra_fn else None,
+                                    extra_fn=extra_fn, want_scatter=want_scatter)
+        if want_scatter:
+            line["scatter_ingest"] = sc_
         sc = line["scatter_ingest"] or {}
         log(f"scatter_ingest: {sc.get('fps')} fps, {sc.get('ms_per_step')} ms/step, {sc.get('bytes_per_peer')} B/peer/step, parity {sc.get('parity')}")
     line["bench_wall_s"] = time.perf_counter() - t_start

@@ -169,6 +169,33 @@ print("NOT REACHED")
     assert "given up" in r.stderr
 
 
+def test_a_hanging_second_workload_costs_the_run_that_block_not_its_line(tmp_path):
+    """Round 6: at N > 1 the second workload's leg (extra_workloads.1080p8) runs with the scatter legs, LAST and under their
+    watchdog -- the driver's multi-GPU run is a one-shot and `value` must not depend on a leg that comes after it.  A leg
+    that hangs (a rank that died in a collective): rank 0 prints the line it has, the missing blocks marked, rc 0."""
+    code = r"""
+import json, sys, time, types
+sys.path.insert(0, %r)
+import bench
+bench.DETAIL_PATH = %r
+full = json.load(open(%r))
+full["n_gpus"] = 8
+full["extra_workloads"] = None
+full["scatter_ingest"] = None
+args = types.SimpleNamespace(scatter_timeout=0.3, extra_timeout=0.2, workload="4k1", backend="gloo", scatter_steps=8)
+bench.scatter_with_watchdog(args, 8, 0, None, None, full, time.perf_counter(), also="1080p8", extra_fn=lambda: time.sleep(30))
+print("NOT REACHED")
+""" % (ROOT, str(tmp_path / "d.json"), os.path.join(ROOT, "tests", "golden", "bench_full_r04_sample.json"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["scatter_ingest"]["parity"] == "timeout"
+    assert j["extra_workloads"] == {"1080p8": None} and j["extra_parity"] == {"1080p8": "timeout"}
+    assert "given up" in r.stderr
+
+
 def test_slim_line_survives_a_run_that_measured_almost_nothing():
     """A leg that failed leaves None behind (the probes of bench.py never break the line): the builder takes any of it."""
     full = {"metric": "m", "value": 1.0, "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1000.0,
