@@ -322,7 +322,7 @@ int main(int argc, char **argv)
         Options o = Options::parse(argc, argv,
             {{"a", "adaptation-coeff"}, {"H", "h-thresh"}, {"S", "s-thresh"}, {"V", "v-thresh"}, {"e", "erode"},
              {"d", "dilate"}, {"T", "timeout"}, {"n", "sigma-noise"}, {"f", "mask"}, {"h", "help"}, {"v", "version"}},
-            {"help", "version", "kalman", "timing"});
+            {"help", "version", "kalman", "timing", "print-partition"});
         if (o.has("version")) { std::cout << "oat-track-hip (MI355X drop-in, liboatgpu ABI " << oatgpu_abi_version() << ")\n"; return 0; }
         if (o.has("help") || o.positional.size() != 2) {
             std::cout << "Usage: oat-track-hip SOURCE[,SOURCE..] SINK[,SINK..] [-a coeff] [-H [lo,hi]] [-S ..] [-V ..] [-e n] [-d n] [--area [min,max]]\n"
@@ -333,12 +333,13 @@ int main(int argc, char **argv)
                          "N SOURCEs / N SINKs: N cameras batched into one device pass per frame; SOURCE i feeds SINK i.\n"
                          "--gpu-index N0,N1,..: the cameras are split into contiguous blocks, one per listed device (own context and thread).\n"
                          "--ingest-root D0 (with --gpu-index D0,D1,..): all frames are ingested on device D0 and scattered to their devices\n"
-                         "       over RCCL send/recv (one process, one thread); --timing prints bytes per peer and ms per step.\n";
+                         "       over RCCL send/recv (one process, one thread); --timing prints bytes per peer and ms per step.\n"
+                         "--print-partition: print which cameras go to which device (both forms) and exit; no device is touched.\n";
             return o.has("help") ? 0 : -1;
         }
         o.apply_config({"adaptation-coeff", "h-thresh", "s-thresh", "v-thresh", "erode", "dilate", "area", "model-file",
                         "kalman", "dt", "timeout", "sigma-accel", "sigma-noise", "gpu-index", "ring", "mask", "thresh", "homography", "stage-copy", "timing",
-                        "ingest-root"}, {"kalman", "timing"});
+                        "ingest-root", "print-partition"}, {"kalman", "timing", "print-partition"});
         const std::vector<std::string> sources = split_list(o.positional[0]), sinks = split_list(o.positional[1]);
         if (sources.size() != sinks.size()) throw std::runtime_error("need as many SINKs as SOURCEs");
         // --gpu-index N | N0,N1,...: one shard of the SOURCE list per listed device (contiguous blocks)
@@ -348,6 +349,15 @@ int main(int argc, char **argv)
             const long v = strtol(d.c_str(), &end, 10);
             if (!end || *end || v < 0 || v > 1023) throw std::runtime_error("--gpu-index: expected N or N0,N1,... (device ordinals)");
             devices.push_back((int)v);
+        }
+        if (o.has("print-partition")) {
+            // which cameras go to which device (camera s -> shard s / ceil(S / N), contiguous blocks, for life) --
+            // printed without touching a device, for both launch forms; tests/test_host_pipeline.py holds it to oat_amd/dist.py
+            const int S = (int)sources.size(), N = (int)devices.size(), per = (S + N - 1) / N;
+            for (int k = 0; k < N && k * per < S; ++k)
+                std::cout << "shard " << k << " device " << devices[k] << " cameras " << k * per << " " << std::min(S, (k + 1) * per)
+                          << (o.has("ingest-root") ? (devices[k] == (int)o.num("ingest-root", 0, 0, 1023) ? " root" : " peer") : "") << "\n";
+            return 0;
         }
         if (o.has("ingest-root")) {                                       // the stream-to-rank scatter over RCCL (scatter_tracker.hpp)
             for (const char *k : {"kalman", "thresh", "mask", "model-file", "homography", "stage-copy"})

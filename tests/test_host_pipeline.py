@@ -63,6 +63,28 @@ def test_ingest_root_arguments_are_checked_before_any_device_is_touched(host_bin
     assert "librccl" in r.stdout and "libamdhip64" in r.stdout and "liboatgpu" in r.stdout, r.stdout      # RCCL behind the C++ boundary
 
 
+@pytest.mark.parametrize("form", ["per-rank ingest", "ingest-root"])
+def test_the_cxx_launchers_partition_is_dist_pys(host_bins, form):
+    """SURVEY 8e: camera s lives on shard s // ceil(S / N) for life.  `oat-track-hip --print-partition` prints what BOTH C++ launch
+    forms do with a SOURCE list and a device list -- no device touched -- and it must be oat_amd.dist.stream_partition (what
+    bench.py's ranks own) for every S and N up to BASELINE configs[3]'s 64 cameras on 8 devices, more devices than cameras
+    included."""
+    from oat_amd.dist import stream_partition
+    B = os.path.join(host_bins, "oat-track-hip")
+    for S, N in [(1, 1), (3, 2), (8, 8), (9, 8), (16, 8), (64, 8), (5, 8), (7, 3), (2, 4)]:
+        devs = ",".join(str(d) for d in range(N))
+        cmd = [B, ",".join(f"c{i}" for i in range(S)), ",".join(f"p{i}" for i in range(S)), "--gpu-index", devs, "--print-partition"]
+        if form == "ingest-root":
+            cmd += ["--ingest-root", "0"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, (S, N, r.stderr)
+        got = [l.split() for l in r.stdout.splitlines() if l.startswith("shard")]
+        want = [(k, stream_partition(S, N, k)) for k in range(N) if len(stream_partition(S, N, k))]
+        assert [(int(g[1]), int(g[3]), int(g[5]), int(g[6])) for g in got] == [(k, k, b.start, b.stop) for k, b in want], (S, N, r.stdout)
+        if form == "ingest-root":
+            assert [g[7] for g in got] == ["root"] + ["peer"] * (len(got) - 1), r.stdout
+
+
 def test_feeder_to_reader_over_shm_without_gpu(host_bins, tmp_path):
     """Token discipline of the transport alone: N frames in -> N tokens seen, in order."""
     # a Position2D-typed reader must refuse a Frame node (Source<T> type check)
