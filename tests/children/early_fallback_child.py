@@ -8,7 +8,7 @@ frame to the global kernels and the context stops parking (oatgpu_early_blob_tim
 
 This process runs `frames` frames through the pipelined device-frame path with the ring kept full, every result against
 the oracle (PositionDetector.cpp:58-99: one token out per token in, in order), then masks and the whole model, and prints one
-JSON line.  argv: rows cols n_streams frames"""
+JSON line.  argv: rows cols n_streams frames [frames_per_launch: 2 = oatgpu_set_fusion(2), both frames of a step park together]"""
 import json
 import os
 import sys
@@ -26,9 +26,12 @@ import oat_amd as A  # noqa: E402
 
 def main():
     rows, cols, n, T = (int(x) for x in sys.argv[1:5])
+    fusion = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     ring = 4
     win = dict(h_thresh=(100, 125), s_thresh=(150, 256), v_thresh=(100, 256))
     hp = A.HotPath(rows, cols, n_streams=n, ring_depth=ring, adaptation_coeff=0.01, erode=3, dilate=5, area=(20.0, 1e6), **win)
+    if fusion == 2:
+        hp.set_fusion(2)
     p = O.hsv_params(h_lo=100, h_hi=125, s_lo=150, s_hi=256, v_lo=100, v_hi=256, erode=3, dilate=5, min_area=20.0, max_area=1e6)
     orc = [O.Mog2(rows, cols, 3) for _ in range(n)]
     rng = np.random.default_rng(77)
@@ -73,7 +76,7 @@ def main():
                                      (m[live] == m_o[live]).all())
     err = hp.lib.oatgpu_last_error(hp.ctx)
     print(json.dumps(dict(results=len(got), mismatches=bad[:8], model_ok=model_ok, timeouts=hp.early_blob_timeouts(), wall_s=wall,
-                          early_steps=sum(1 for _, e in shapes if e), steps=len(shapes), last_error=(err.decode() if err else ""),
+                          early_steps=sum(1 for _, e in shapes if e), steps=len(shapes), last_error=(err.decode() if err else ""), fusion=fusion,
                           env={k: os.environ.get(k) for k in ("AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")})))
     hp.close()
 

@@ -1422,7 +1422,7 @@ def test_early_blob_dispatch_equals_the_plain_path(A, fusion, ring, kalman):
     assert [hp.collect(), hp.collect()] == [ref.collect(), ref.collect()]
 
 
-@pytest.mark.parametrize("shape", [(2160, 3840, 1), (1080, 1920, 2)])
+@pytest.mark.parametrize("shape", [(2160, 3840, 1, 1), (1080, 1920, 2, 1), (2160, 3840, 1, 2)])
 def test_early_order_survives_a_tool_that_serialises_dispatches(shape):
     """the default path of ONE stream of >= 4 MP (and of two 1080p streams) parks a blob workgroup that
     waits on the device for a ticket a later kernel publishes -- two kernels resident at once, which HIP does not promise.
@@ -1436,9 +1436,9 @@ def test_early_order_survives_a_tool_that_serialises_dispatches(shape):
     import subprocess
     import sys
     import tempfile
-    rows, cols, n = shape
+    rows, cols, n, fusion = shape                  # fusion 2: both frames of a step park together -- still ONE episode
     child = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "children", "early_fallback_child.py"),
-             str(rows), str(cols), str(n), "44"]
+             str(rows), str(cols), str(n), "44", str(fusion)]
     base = {k: v for k, v in os.environ.items() if k not in ("AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")}
     modes = [("plain", {}, []), ("AMD_SERIALIZE_KERNEL=3", {"AMD_SERIALIZE_KERNEL": "3"}, []), ("HIP_LAUNCH_BLOCKING=1", {"HIP_LAUNCH_BLOCKING": "1"}, [])]
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -1458,13 +1458,13 @@ def test_early_order_survives_a_tool_that_serialises_dispatches(shape):
                 assert "early blob dispatch switched off" in j["last_error"], (name, j)
                 assert j["early_steps"] < j["steps"], (name, j)            # the steps behind the episode took the plain order
             assert j["wall_s"] < (2.0 if not prefix else 30.0) + 0.15 * j["timeouts"], (name, j)    # (a profiler's own cost aside)
-        assert seen["plain"]["timeouts"] == 0 and seen["plain"]["early_steps"] >= 40, seen["plain"]   # the path under test IS the default
+        assert seen["plain"]["timeouts"] == 0 and seen["plain"]["early_steps"] >= (40 if fusion == 1 else 20), seen["plain"]   # the path under test IS the default
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         try:
             os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
             with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
-                                   "early_fallback_%dx%dx%d.json" % shape), "w") as f:
+                                   "early_fallback_%dx%dx%d_fusion%d.json" % shape), "w") as f:
                 json.dump(seen, f, indent=1)
         except OSError:
             pass
